@@ -1,0 +1,18 @@
+"""MI355X-native Gibbs engine for the `sample!` hot path of ExtendedRtIrtModeling.jl.
+
+Export list mirrors the part of /root/reference/src/ExtendedRtIrtModeling.jl:33-77 that belongs to the hot path.
+"""
+from .base import InputData, InputData4R, InputPara, OutputDic, SimConditions, setCond
+from .gibbs import (GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCrossQr, GibbsRtIrtLatentQr, GibbsRtIrtQuantile, coef, getDic,
+                    getLogLikelihood, precis, sample, sample_b)
+from .simtools import (getBias, getRmse, setDataMlIrt, setDataRtIrt, setDataRtIrtCross, setDataRtIrtLatent,
+                       setTrueParaMlIrt, setTrueParaRtIrt, setTrueParaRtIrtCross, setTrueParaRtIrtLatent)
+from . import _lib, parallel
+
+__all__ = [
+    "setCond", "SimConditions", "InputData", "InputData4R", "InputPara", "OutputDic",
+    "setDataMlIrt", "setDataRtIrt", "setDataRtIrtCross", "setDataRtIrtLatent",
+    "setTrueParaMlIrt", "setTrueParaRtIrt", "setTrueParaRtIrtCross", "setTrueParaRtIrtLatent",
+    "getBias", "getRmse", "getDic", "getLogLikelihood", "sample_b", "sample",
+    "GibbsMlIrt", "GibbsRtIrt", "GibbsRtIrtCrossQr", "GibbsRtIrtLatentQr", "GibbsRtIrtQuantile", "coef", "precis",
+]

@@ -1,0 +1,226 @@
+"""ctypes binding of libertirt.so (include/ertirt.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libertirt.so")
+
+MODEL_MLIRT, MODEL_RTIRT, MODEL_CROSSQR, MODEL_LATENTQR = 0, 1, 2, 3
+PREC_F32, PREC_F64 = 0, 1
+TRACE_SUMMARY, TRACE_FULL = 0, 1
+TRACE_RA, TRACE_RT, TRACE_QR, TRACE_LOGLIKE = 0, 1, 2, 3
+
+EXPORTS = [
+    "erm_create", "erm_destroy", "erm_set_data", "erm_set_state", "erm_get_state", "erm_run", "erm_rows_done",
+    "erm_reset_trace", "erm_trace_width", "erm_get_trace", "erm_item_trace_width", "erm_get_item_trace", "erm_get_mean",
+    "erm_post_count", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample",
+]
+
+
+class ErmError(RuntimeError):
+    pass
+
+
+class erm_config(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("n_item", C.c_int32), ("n_subj", C.c_int64), ("n_feat", C.c_int32), ("n_iter", C.c_int32),
+        ("n_chain", C.c_int32), ("n_burnin", C.c_int32), ("intercept", C.c_int32), ("one_pl", C.c_int32),
+        ("cov2one", C.c_int32), ("sigp_mode", C.c_int32), ("chain_id", C.c_int32), ("q_rt", C.c_double),
+        ("seed", C.c_uint64), ("device", C.c_int32), ("precision", C.c_int32), ("trace_mode", C.c_int32),
+        ("lanes_per_row", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32), ("profile", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_DP = C.POINTER(C.c_double)
+
+
+class erm_state(C.Structure):
+    _fields_ = [(n, _DP) for n in ("theta", "a", "b", "zeta", "lambda_", "sig2t", "beta", "sigp", "rho", "nu")]
+
+
+class erm_timing(C.Structure):
+    _fields_ = [
+        ("run_ms", C.c_double), ("pass_ms_total", C.c_double), ("pass_launches", C.c_int64), ("sweeps", C.c_int64),
+        ("lanes_per_row", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32), ("lds_bytes", C.c_int32),
+        ("cu_count", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libertirt.so; raises ErmError if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ErmError(f"HIP extension missing: {LIB_PATH} (build it with `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    lib.erm_create.argtypes = [C.POINTER(erm_config), C.POINTER(H)]
+    lib.erm_destroy.argtypes = [H]
+    lib.erm_destroy.restype = None
+    lib.erm_set_data.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.erm_set_state.argtypes = [H, C.POINTER(erm_state)]
+    lib.erm_get_state.argtypes = [H, C.POINTER(erm_state)]
+    lib.erm_run.argtypes = [H, C.c_int64]
+    lib.erm_rows_done.argtypes = [H]
+    lib.erm_rows_done.restype = C.c_int64
+    lib.erm_reset_trace.argtypes = [H]
+    lib.erm_trace_width.argtypes = [H, C.c_int]
+    lib.erm_trace_width.restype = C.c_int64
+    lib.erm_get_trace.argtypes = [H, C.c_int, C.c_void_p]
+    lib.erm_item_trace_width.argtypes = [H]
+    lib.erm_item_trace_width.restype = C.c_int64
+    lib.erm_get_item_trace.argtypes = [H, C.c_void_p]
+    lib.erm_get_mean.argtypes = [H, C.POINTER(erm_state)]
+    lib.erm_post_count.argtypes = [H]
+    lib.erm_post_count.restype = C.c_int64
+    lib.erm_get_timing.argtypes = [H, C.POINTER(erm_timing)]
+    lib.erm_last_error.restype = C.c_char_p
+    lib.erm_version.restype = C.c_char_p
+    lib.erm_debug_sample.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise ErmError(f"libertirt error {rc}: {load().erm_last_error().decode()}")
+
+
+STATE_FIELDS = ("theta", "a", "b", "zeta", "lambda_", "sig2t", "beta", "sigp", "rho", "nu")
+
+
+def state_struct(arrays: dict):
+    """Build an erm_state from {field: float64 contiguous ndarray or None}; returns (struct, keepalive)."""
+    st = erm_state()
+    keep = []
+    for f in STATE_FIELDS:
+        v = arrays.get(f)
+        if v is None:
+            setattr(st, f, None)
+        else:
+            assert v.dtype == np.float64 and (v.flags["C_CONTIGUOUS"] or v.flags["F_CONTIGUOUS"])
+            keep.append(v)
+            setattr(st, f, v.ctypes.data_as(_DP))
+    return st, keep
+
+
+class Engine:
+    """Thin RAII wrapper over an erm_handle."""
+
+    def __init__(self, **kw):
+        lib = load()
+        cfg = erm_config()
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown config field {k}")
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib.erm_create(C.byref(cfg), C.byref(self._h)))
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.erm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data / state
+    def set_data(self, Y, logT=None, X=None):
+        Ya = np.asarray(Y)
+        if Ya.dtype != np.bool_ and not np.all((Ya == 0) | (Ya == 1)):
+            raise ValueError("Y must contain only 0/1")
+        Yf = np.asfortranarray(Ya.astype(np.uint8))
+        lt = None if logT is None else np.asfortranarray(logT, dtype=np.float64)
+        xx = None if X is None or np.size(X) == 0 else np.asfortranarray(X, dtype=np.float64)
+        check(self._lib.erm_set_data(self._h, Yf.ctypes.data, None if lt is None else lt.ctypes.data,
+                                     None if xx is None else xx.ctypes.data))
+
+    def set_state(self, **arrays):
+        arrs = {k: (None if v is None else np.asfortranarray(v, dtype=np.float64)) for k, v in arrays.items()}
+        st, keep = state_struct(arrs)
+        check(self._lib.erm_set_state(self._h, C.byref(st)))
+
+    def _state_buffers(self, which=None):
+        c = self.cfg
+        N, J, F = c.n_subj, c.n_item, c.n_feat
+        nb = {MODEL_MLIRT: F + 1, MODEL_RTIRT: 2 * (F + 1), MODEL_LATENTQR: F + 2, MODEL_CROSSQR: 0}[c.model]
+        nnu = {MODEL_LATENTQR: N, MODEL_CROSSQR: N * J}.get(c.model, 0)
+        sizes = dict(theta=N, a=J, b=J, zeta=N, lambda_=J, sig2t=J, beta=nb, sigp=4, rho=J, nu=nnu)
+        return {k: (np.zeros(n, dtype=np.float64) if n and (which is None or k in which) else None) for k, n in sizes.items()}
+
+    def get_state(self, which=None):
+        bufs = self._state_buffers(which)
+        st, keep = state_struct(bufs)
+        check(self._lib.erm_get_state(self._h, C.byref(st)))
+        return bufs
+
+    def get_mean(self, which=None):
+        bufs = self._state_buffers(which)
+        st, keep = state_struct(bufs)
+        check(self._lib.erm_get_mean(self._h, C.byref(st)))
+        return bufs
+
+    # ---- run / outputs
+    def run(self, nsweeps: int):
+        check(self._lib.erm_run(self._h, int(nsweeps)))
+
+    def reset_trace(self):
+        check(self._lib.erm_reset_trace(self._h))
+
+    @property
+    def rows_done(self):
+        return int(self._lib.erm_rows_done(self._h))
+
+    @property
+    def post_count(self):
+        return int(self._lib.erm_post_count(self._h))
+
+    def trace(self, which: int):
+        """Post.ra / rt / qr / logLike as an (nIter, width, nChain) Fortran-ordered array (Julia layout)."""
+        w = int(self._lib.erm_trace_width(self._h, which))
+        if w <= 0:
+            return np.zeros((0,), dtype=np.float64)
+        out = np.empty((self.cfg.n_iter, w, self.cfg.n_chain), dtype=np.float64, order="F")
+        check(self._lib.erm_get_trace(self._h, which, out.ctypes.data))
+        return out
+
+    def item_trace(self):
+        w = int(self._lib.erm_item_trace_width(self._h))
+        out = np.empty((self.rows_done, w), dtype=np.float64)
+        if out.size:
+            check(self._lib.erm_get_item_trace(self._h, out.ctypes.data))
+        return out
+
+    def timing(self):
+        t = erm_timing()
+        check(self._lib.erm_get_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in erm_timing._fields_}
+
+
+def debug_sample(which, n, par0=None, par1=None, *, seed=1234, site=15, sweep=1, precision=PREC_F64, device=0):
+    lib = load()
+    out = np.empty(n, dtype=np.float64)
+    p0 = None if par0 is None else np.ascontiguousarray(par0, dtype=np.float64)
+    p1 = None if par1 is None else np.ascontiguousarray(par1, dtype=np.float64)
+    check(lib.erm_debug_sample(device, precision, which, seed, site, sweep, n,
+                               None if p0 is None else p0.ctypes.data, None if p1 is None else p1.ctypes.data, out.ctypes.data))
+    return out

@@ -1,0 +1,725 @@
+// erm_kernels.hpp -- the Gibbs sweep as gfx950 kernels.
+//
+// One reference sweep (/root/reference/src/GibbsRtIrt.pl.jl:289-324 and siblings) is re-scheduled, without changing any
+// conditional or its conditioning values, into
+//     tiny step  : one workgroup; reduces the previous pass's per-workgroup statistics slabs in a fixed order and makes
+//                  every item-level / structural draw (beta, Sigma_p, b, a, lambda, sigma2_t, rho) from sufficient statistics;
+//     row pass   : ONE streaming pass over (omega, Y, logT[, nu]) that draws theta_i, zeta_i for every subject, then the
+//                  NEXT sweep's omega_ij (and nu) -- whose conditioning values are final at that point -- and accumulates
+//                  the statistics the next tiny step needs plus this sweep's log-likelihood.
+// GibbsRtIrtCrossQr needs two passes per sweep because lambda_t depends on theta_t (src/Draw.pl.jl:239-251).
+//
+// Thread mapping of a pass: a wave holds R = 64/W subjects x W lanes; lane (r, s) owns items j = s + W k, k < ceil(J/W).
+// Row sums are W-lane butterflies, item sums are R-lane butterflies followed by wave-private fp64 LDS accumulators, so all
+// reductions are order-deterministic: a chain is bit-reproducible run to run.
+// HBM layout: Y u8 [N][J], centred logT / omega / nu `real` [N][J] (row-major), theta/zeta `real` [N].
+#pragma once
+#include "erm_rng.hpp"
+
+namespace erm {
+
+enum Model : int { MLIRT = 0, RTIRT = 1, CROSSQR = 2, LATENTQR = 3 };
+
+constexpr int PMAX = 16;            // max columns of the latent-regression design ([1 X theta])
+constexpr int NITEMARR = 8;         // per-item arrays staged in LDS
+
+struct Ctl {
+    uint32_t sweep;       // global index of the sweep whose item draws are current
+    uint32_t row;         // trace row of that sweep within the current sample! call
+    uint32_t burn_rows;   // rows < burn_rows are burn-in (not accumulated into Post.mean)
+    uint32_t err;         // sticky non-finite flag
+};
+
+// parameter block written by the tiny step (fp64): a, b, lambda, sig2t, rho : 5 x J, then Sigp(4), beta(2*PMAX)
+__host__ __device__ inline int par_off_sigp(int J) { return 5 * J; }
+__host__ __device__ inline int par_off_beta(int J) { return 5 * J + 4; }
+__host__ __device__ inline int par_size(int J) { return 5 * J + 4 + 2 * PMAX; }
+
+// data constants (fp64): K0[J], m[J] (column means of logT), csq[J] (sum of squared centred logT), muLam, sdLam, XtX[PMAX*PMAX]
+__host__ __device__ inline int cst_off_k0(int) { return 0; }
+__host__ __device__ inline int cst_off_m(int J) { return J; }
+__host__ __device__ inline int cst_off_csq(int J) { return 2 * J; }
+__host__ __device__ inline int cst_off_mu(int J) { return 3 * J; }
+__host__ __device__ inline int cst_off_xtx(int J) { return 3 * J + 2; }
+__host__ __device__ inline int cst_size(int J) { return 3 * J + 2 + PMAX * PMAX; }
+
+// statistics layout of one slab row: NSTAT item statistics x J, then NG globals
+template <int MODEL, int PHASE> struct Stats;
+template <> struct Stats<MLIRT, 0>    { static constexpr int NSTAT = 4; __host__ __device__ static int ng(int p) { return p + 1; } };        // S0 S1 S2 K1 | x'theta, LL
+template <> struct Stats<RTIRT, 0>    { static constexpr int NSTAT = 5; __host__ __device__ static int ng(int p) { return 2 * p + 4; } };    // + G | x'theta, x'zeta, tt, tz, zz, LL
+template <> struct Stats<LATENTQR, 0> { static constexpr int NSTAT = 5; __host__ __device__ static int ng(int p) { return 2 * p + 8; } };    // | x'theta, tt, x'u, tu, uu, snu, snu2, sz, zz, LL
+template <> struct Stats<CROSSQR, 0>  { static constexpr int NSTAT = 8; __host__ __device__ static int ng(int) { return 1; } };              // S0 S1 S2 K1 W0 W1 W2 V | LL_A
+template <> struct Stats<CROSSQR, 1>  { static constexpr int NSTAT = 2; __host__ __device__ static int ng(int) { return 2; } };              // R0 R1 | zz, LL_B
+
+template <typename real> struct PassArgs {
+    const uint8_t* Y; const real* C; real* omega; real* nu; const real* X;
+    real* theta; real* zeta;
+    const double* par; const double* cst; double* slab; const Ctl* ctl;
+    double* sum_theta; double* sum_zeta; double* sum_nu;
+    real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] or nullptr
+    long long N; int J; int nFeat; int W; int logW; int IPL;
+    int mode;             // 0 = prologue (no theta/zeta draws, no LL, no trace), 1 = full sweep pass
+    uint32_t chain; uint64_t seed; double k1, k2;
+};
+
+template <typename T> __device__ __forceinline__ T bfly_sum(T v, int lo, int hi)   // sum over lanes differing in bits [lo, hi)
+{
+    for (int m = lo; m < hi; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float  log1pexp_r(float x)  { return x > 0.f ? x + log1pf(__expf(-x)) : log1pf(__expf(x)); }
+__device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+
+constexpr double LOG_2PI = 1.8378770664093454836;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row pass.  blockDim.x = 64 * nWaves.  Dynamic LDS: item arrays (real), structural scalars, per-wave accumulators.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODEL, typename real, int PHASE>
+__global__ void __launch_bounds__(1024) pass_kernel(PassArgs<real> A)
+{
+    using ST = Stats<MODEL, PHASE>;
+    constexpr int NSTAT = ST::NSTAT;
+    const int J = A.J, W = A.W, R = 64 / W, IPL = A.IPL;
+    const int p = A.nFeat + 1;                       // [1 X]
+    const int NG = ST::ng(p);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const int s = lane & (W - 1), r = lane >> A.logW;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* sh_d = reinterpret_cast<double*>(smem);
+    double* sh_struct = sh_d;                                   // 8 + 2*PMAX doubles
+    double* sh_acc = sh_struct + 8 + 2 * PMAX;                  // [nWaves][NSTAT][J]
+    double* sh_gacc = sh_acc + (size_t)nWaves * NSTAT * J;      // [nWaves][NG][R]
+    double* sh_ll = sh_gacc + (size_t)nWaves * NG * R;          // [nWaves]
+    real* sh_item = reinterpret_cast<real*>(sh_ll + nWaves);    // [NITEMARR][J]
+    real* sh_a = sh_item, *sh_b = sh_item + J, *sh_a2 = sh_item + 2 * J, *sh_a2b = sh_item + 3 * J;
+    real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
+
+    const uint32_t sweep = A.ctl->sweep;
+    const uint32_t trow = A.ctl->row;
+    const bool post_burn = trow >= A.ctl->burn_rows;
+
+    // ---- stage item parameters and structural scalars
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        const double a = A.par[j], b = A.par[J + j], lam = A.par[2 * J + j], sg = A.par[3 * J + j], rho = A.par[4 * J + j];
+        sh_a[j] = (real)a; sh_b[j] = (real)b; sh_a2[j] = (real)(a * a); sh_a2b[j] = (real)(a * a * b);
+        sh_lamc[j] = (real)(lam - A.cst[cst_off_m(J) + j]); sh_isig[j] = (real)(1.0 / sg); sh_lsig[j] = (real)log(sg); sh_rho[j] = (real)rho;
+    }
+    if (threadIdx.x < 8 + 2 * PMAX) {
+        double v = 0.0;
+        if (threadIdx.x < 4) v = A.par[par_off_sigp(J) + threadIdx.x];
+        else if (threadIdx.x >= 8) v = A.par[par_off_beta(J) + threadIdx.x - 8];
+        else if (threadIdx.x == 4) { double t = 0.0; for (int j = 0; j < J; ++j) t += 1.0 / A.par[3 * J + j]; v = t; }   // sum_j 1/sig2t_j
+        sh_struct[threadIdx.x] = v;
+    }
+    for (int e = threadIdx.x; e < nWaves * (NSTAT * J + NG * R + 1); e += blockDim.x) sh_acc[e] = 0.0;
+    __syncthreads();
+
+    const real sig11 = (MODEL == MLIRT) ? real(1) : (real)sh_struct[0];
+    const real sig22 = (real)sh_struct[3];
+    const real sum_isig = (real)sh_struct[4];
+    const double* beta = sh_struct + 8;
+    const real k1 = (real)A.k1, k2 = (real)A.k2;
+    double* acc = sh_acc + (size_t)wave * NSTAT * J;
+    double* gacc = sh_gacc + (size_t)wave * NG * R;
+    double ll = 0.0;
+
+    const long long nGroups = (A.N + R - 1) / R;
+    for (long long g = (long long)blockIdx.x * nWaves + wave; g < nGroups; g += (long long)gridDim.x * nWaves) {
+        const long long i = g * R + r;
+        const bool rowok = i < A.N;
+        const size_t base = (size_t)(rowok ? i : 0) * J;
+
+        // ---------------- row phase: sums over the subject's items
+        real sA = 0, sB = 0, sC = 0, sD = 0;
+        if (PHASE == 0) {
+            if (rowok) for (int k = 0; k < IPL; ++k) {
+                const int j = s + W * k;
+                if (j < J) {
+                    const real w = A.omega[base + j];
+                    const real kap = (real)A.Y[base + j] - real(0.5);
+                    sA += sh_a2[j] * w;
+                    sB += sh_a[j] * kap + sh_a2b[j] * w;
+                    if (MODEL == RTIRT || MODEL == LATENTQR) sC += (sh_lamc[j] - A.C[base + j]) * sh_isig[j];
+                }
+            }
+            sA = bfly_sum(sA, 1, W); sB = bfly_sum(sB, 1, W);
+            if (MODEL == RTIRT || MODEL == LATENTQR) sC = bfly_sum(sC, 1, W);
+        } else {   // CrossQr pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202)
+            const real th = rowok ? A.theta[i] : real(0);
+            if (rowok) for (int k = 0; k < IPL; ++k) {
+                const int j = s + W * k;
+                if (j < J) {
+                    const real nu = A.nu[base + j];
+                    const real iden = sh_isig[j] / (k2 * nu);
+                    sD += iden;
+                    sC += (sh_lamc[j] - A.C[base + j] - th * sh_rho[j] + k1 * nu) * iden;
+                }
+            }
+            sC = bfly_sum(sC, 1, W); sD = bfly_sum(sD, 1, W);
+        }
+
+        // ---------------- row draws (computed redundantly by the W lanes of the row)
+        real th = rowok ? A.theta[i] : real(0);
+        real ze = (MODEL != MLIRT && rowok) ? A.zeta[i] : real(0);
+        real nu_row = real(1), xb5 = real(0);
+        real x[PMAX];                                       // design row [1 X], statically indexed
+#pragma unroll
+        for (int u = 0; u < PMAX; ++u) x[u] = (u == 0) ? real(1) : ((u < p && rowok) ? A.X[(size_t)i * A.nFeat + (u - 1)] : real(0));
+
+        if (A.mode == 1 && rowok) {
+            if (PHASE == 0) {
+                // theta: src/Draw.pl.jl:49-62 (prior x*beta[:,1]) / :67-80 (Null prior)
+                real mu0 = 0;
+                if (MODEL == MLIRT || MODEL == RTIRT) {
+#pragma unroll
+                    for (int u = 0; u < PMAX; ++u) if (u < p) mu0 += x[u] * (real)beta[u];
+                }
+                const real parV = real(1) / (real(1) / sig11 + sA);
+                const real parM = parV * (mu0 / sig11 + sB);
+                Stream st(A.seed, A.chain, SITE_THETA, (uint32_t)i, 0u, sweep);
+                th = parM + r_sqrt(parV) * normal<real>(st);
+            }
+            if (MODEL == RTIRT || MODEL == LATENTQR) {
+                // zeta: src/Draw.pl.jl:132-141 / :161-174
+                real mu0 = 0, s0 = sig22;
+                if (MODEL == RTIRT) {
+#pragma unroll
+                    for (int u = 0; u < PMAX; ++u) if (u < p) mu0 += x[u] * (real)beta[PMAX + u];
+                } else {
+                    nu_row = A.nu[i];
+#pragma unroll
+                    for (int u = 0; u < PMAX; ++u) if (u < p) xb5 += x[u] * (real)beta[u];
+                    xb5 += th * (real)beta[p];
+                    mu0 = xb5 + k1 * nu_row;
+                    s0 = sig22 * (k2 * nu_row);
+                }
+                const real parV = real(1) / (real(1) / s0 + sum_isig);
+                const real parM = parV * (mu0 / s0 + sC);
+                Stream st(A.seed, A.chain, SITE_ZETA, (uint32_t)i, 0u, sweep);
+                ze = parM + r_sqrt(parV) * normal<real>(st);
+            }
+            if (MODEL == CROSSQR && PHASE == 1) {
+                // zeta: src/Draw.pl.jl:192-206 (zero prior mean, prior variance Sigp[2,2])
+                const real parV = real(1) / (real(1) / sig22 + sD);
+                const real parM = parV * sC;
+                Stream st(A.seed, A.chain, SITE_ZETA, (uint32_t)i, 0u, sweep);
+                ze = parM + r_sqrt(parV) * normal<real>(st);
+            }
+        } else if (MODEL == LATENTQR && rowok) {
+            nu_row = A.nu ? A.nu[i] : real(1);
+#pragma unroll
+            for (int u = 0; u < PMAX; ++u) if (u < p) xb5 += x[u] * (real)beta[u];
+            xb5 += th * (real)beta[p];
+        }
+
+        // ---------------- per-row outputs, structural log-likelihood, next-sweep nu (LatentQr), global statistics
+        real nu_next = real(1);
+        if (MODEL == LATENTQR && rowok) {
+            // nu_{t+1}: src/Draw.pl.jl:325-343 (depends on zeta_t, theta_t, beta_t, Sigp_t only)
+            const real den = r_sqrt(sig22 * k2);
+            const real parA = r_abs(ze - xb5) / den;
+            const real parB = r_sqrt(real(2) * k2 + k1 * k1) / den;
+            Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, 0u, sweep + 1u);
+            nu_next = qr_weight<real>(st, parA, parB);
+        }
+        if (rowok && s == 0) {
+            if (A.mode == 1) {
+                if (PHASE == 0) {
+                    A.theta[i] = th;
+                    if (A.tr_theta) A.tr_theta[(size_t)trow * A.N + i] = th;
+                    if (post_burn) A.sum_theta[i] += (double)th;
+                }
+                if ((MODEL == RTIRT || MODEL == LATENTQR) || (MODEL == CROSSQR && PHASE == 1)) {
+                    A.zeta[i] = ze;
+                    if (A.tr_zeta) A.tr_zeta[(size_t)trow * A.N + i] = ze;
+                    if (post_burn) A.sum_zeta[i] += (double)ze;
+                }
+                // structural log-likelihood terms (src/GibbsRtIrt.pl.jl:201,269; src/GibbsRtIrtLatent.pl.jl:261)
+                if (MODEL == MLIRT) {
+                    real mu = 0;
+#pragma unroll
+                    for (int u = 0; u < PMAX; ++u) if (u < p) mu += x[u] * (real)beta[u];
+                    const real e = th - mu;
+                    ll += -0.5 * LOG_2PI - 0.5 * (double)(e * e);
+                } else if (MODEL == RTIRT || (MODEL == CROSSQR && PHASE == 1)) {
+                    real m0 = 0, m1 = 0;
+                    if (MODEL == RTIRT) {
+#pragma unroll
+                        for (int u = 0; u < PMAX; ++u) if (u < p) { m0 += x[u] * (real)beta[u]; m1 += x[u] * (real)beta[PMAX + u]; }
+                    }
+                    const double s00 = sh_struct[0], s10 = sh_struct[1], s01 = sh_struct[2], s11 = sh_struct[3];
+                    const double det = s00 * s11 - s10 * s01;
+                    const double e0 = (double)(th - m0), e1 = (double)(ze - m1);
+                    const double q = (s11 * e0 * e0 - (s10 + s01) * e0 * e1 + s00 * e1 * e1) / det;
+                    ll += -LOG_2PI - 0.5 * log(det) - 0.5 * q;
+                } else if (MODEL == LATENTQR) {
+                    const double var = (double)sig22 * ((double)k2 * (double)nu_row);
+                    const double e = (double)(ze - (xb5 + k1 * nu_row));
+                    ll += -0.5 * LOG_2PI - 0.5 * log(var) - 0.5 * e * e / var;
+                    if (A.tr_nu) A.tr_nu[(size_t)trow * A.N + i] = nu_row;
+                    if (post_burn) A.sum_nu[i] += (double)nu_row;
+                }
+            }
+            if (MODEL == LATENTQR) A.nu[i] = nu_next;
+            // global statistics for the next tiny step (lane-private LDS slots: gacc[g][r])
+            if (PHASE == 0 && MODEL != CROSSQR) {
+                int o = 0;
+#pragma unroll
+                for (int u = 0; u < PMAX; ++u) if (u < p) gacc[(o + u) * R + r] += (double)x[u] * (double)th;
+                o += p;
+                if (MODEL == RTIRT) {
+#pragma unroll
+                    for (int u = 0; u < PMAX; ++u) if (u < p) gacc[(o + u) * R + r] += (double)x[u] * (double)ze;
+                    o += p;
+                    gacc[(o + 0) * R + r] += (double)th * (double)th;
+                    gacc[(o + 1) * R + r] += (double)th * (double)ze;
+                    gacc[(o + 2) * R + r] += (double)ze * (double)ze;
+                } else if (MODEL == LATENTQR) {
+                    const double uu = (double)ze - (double)k1 * (double)nu_next;
+                    gacc[(o + 0) * R + r] += (double)th * (double)th; o += 1;
+#pragma unroll
+                    for (int u = 0; u < PMAX; ++u) if (u < p) gacc[(o + u) * R + r] += (double)x[u] * uu;
+                    o += p;
+                    gacc[(o + 0) * R + r] += (double)th * uu;
+                    gacc[(o + 1) * R + r] += uu * uu;
+                    gacc[(o + 2) * R + r] += (double)nu_next;
+                    gacc[(o + 3) * R + r] += (double)nu_next * (double)nu_next;
+                    gacc[(o + 4) * R + r] += (double)ze;
+                    gacc[(o + 5) * R + r] += (double)ze * (double)ze;
+                }
+            }
+            if (MODEL == CROSSQR && PHASE == 1) gacc[0 * R + r] += (double)ze * (double)ze;
+        }
+
+        // ---------------- cell phase: log-likelihood, next-sweep omega / nu, item statistics
+        for (int k = 0; k < IPL; ++k) {
+            const int j = s + W * k;
+            const bool ok = rowok && j < J;
+            real v[NSTAT];
+#pragma unroll
+            for (int q = 0; q < NSTAT; ++q) v[q] = 0;
+            if (ok) {
+                if constexpr (PHASE == 0) {
+                    const real a = sh_a[j], b = sh_b[j];
+                    const real eta = a * (th - b);
+                    const bool y = A.Y[base + j] != 0;
+                    const real kap = y ? real(0.5) : real(-0.5);
+                    real c = 0;
+                    if (MODEL != MLIRT) c = A.C[base + j];
+                    if (A.mode == 1) {
+                        ll += (double)((y ? eta : real(0)) - log1pexp_r(eta));
+                        if (MODEL == RTIRT || MODEL == LATENTQR) {
+                            const real e = c + ze - sh_lamc[j];
+                            ll += -0.5 * LOG_2PI - 0.5 * (double)(sh_lsig[j] + e * e * sh_isig[j]);
+                        }
+                    }
+                    // omega_{t+1} | theta_t, a_t, b_t : src/Draw.pl.jl:36-40
+                    Stream st(A.seed, A.chain, SITE_OMEGA, (uint32_t)i, (uint32_t)j, sweep + 1u);
+                    const real w = pg1<real>(st, eta);
+                    A.omega[base + j] = w;
+                    v[0] = w; v[1] = w * th; v[2] = w * th * th; v[3] = kap * th;
+                    if constexpr (MODEL == RTIRT || MODEL == LATENTQR) v[4] = c * ze;
+                    if constexpr (MODEL == CROSSQR) {
+                        // statistics for lambda_t, sig2t_t (src/Draw.pl.jl:246-247, 285) with nu_t, zeta_{t-1}, theta_t, rho_t
+                        const real nu = A.nu[base + j];
+                        const real rr = c + ze + th * sh_rho[j] - k1 * nu;
+                        const real inu = real(1) / nu;
+                        v[4] = inu; v[5] = rr * inu; v[6] = rr * rr * inu; v[7] = nu;
+                    }
+                } else {
+                    // CrossQr pass B: RT log-likelihood with nu_t, then nu_{t+1} (src/Draw.pl.jl:303-320) and rho statistics (:484-485)
+                    const real c = A.C[base + j];
+                    const real nu = A.nu[base + j];
+                    const real rho = sh_rho[j];
+                    if (A.mode == 1) {
+                        const real var_ = k2 * nu;                                   // times sig2t_j
+                        const real e = c - sh_lamc[j] + ze + th * rho - k1 * nu;   // logT - mu_t
+                        ll += -0.5 * LOG_2PI - 0.5 * (double)(sh_lsig[j] + r_log(var_) + e * e * sh_isig[j] / var_);
+                        if (post_burn && A.sum_nu) A.sum_nu[base + j] += (double)nu;
+                    }
+                    const real den = r_sqrt(k2) / r_sqrt(sh_isig[j]);               // sqrt(sig2t k2)
+                    const real parA = r_abs(c - sh_lamc[j] + ze + th * rho) / den;
+                    const real parB = r_sqrt(real(2) * k2 + k1 * k1) / den;
+                    Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, (uint32_t)j, sweep + 1u);
+                    const real nun = qr_weight<real>(st, parA, parB);
+                    A.nu[base + j] = nun;
+                    const real inu = real(1) / nun;
+                    v[0] = th * th * inu;
+                    v[1] = th * (sh_lamc[j] - ze - c + k1 * nun) * inu;
+                }
+            }
+            // sum over the R subjects of the wave, then accumulate in the wave's fp64 LDS slots
+#pragma unroll
+            for (int q = 0; q < NSTAT; ++q) v[q] = bfly_sum(v[q], W, 64);
+            if (r == 0 && j < J) {
+#pragma unroll
+                for (int q = 0; q < NSTAT; ++q) acc[q * J + j] += (double)v[q];
+            }
+        }
+    }
+
+    // ---------------- block epilogue: fixed-order reduction of the wave accumulators into this block's slab row
+    ll = bfly_sum(ll, 1, 64);
+    if (lane == 0) sh_ll[wave] = ll;
+    __syncthreads();
+    const int NS = NSTAT * J + NG;
+    double* out = A.slab + (size_t)blockIdx.x * NS;
+    for (int e = threadIdx.x; e < NS; e += blockDim.x) {
+        double t = 0.0;
+        if (e < NSTAT * J) {
+            for (int w = 0; w < nWaves; ++w) t += sh_acc[(size_t)w * NSTAT * J + e];
+        } else if (e < NS - 1) {
+            const int gi = e - NSTAT * J;
+            for (int w = 0; w < nWaves; ++w)
+                for (int rr = 0; rr < R; ++rr) t += sh_gacc[(size_t)w * NG * R + gi * R + rr];
+        } else {
+            for (int w = 0; w < nWaves; ++w) t += sh_ll[w];
+        }
+        out[e] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tiny step
+// ---------------------------------------------------------------------------------------------------------------------
+struct TinyArgs {
+    double* par; const double* cst; const double* slab0; const double* slab1; Ctl* ctl;
+    double* tr_item;      // [rows][4J + NQ] : a, b, lambda, sig2t, then the small part of qr
+    double* tr_ll;        // [rows]
+    long long N; int J; int nFeat; int nb0, nb1;
+    int mode;             // 0 = draw sweep (advance ctl), 1 = final (only reduce the last pass's log-likelihood)
+    int first;            // 1 if no full pass precedes this step in the current sample! call
+    int intercept, onepl, cov2one, sigp_mode;
+    uint32_t chain; uint64_t seed; double k1, k2;
+    int nq;               // number of small qr entries recorded per sweep
+};
+
+// dense helpers on tiny matrices (column-major, n <= 2*PMAX), executed by one thread
+__device__ inline void d_inverse(int n, const double* Ain, double* Ainv, double* work /* n*2n */)
+{
+    const int n2 = 2 * n;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { work[i * n2 + j] = Ain[i + j * n]; work[i * n2 + n + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < n; ++c) {
+        int piv = c; double best = fabs(work[c * n2 + c]);
+        for (int rr = c + 1; rr < n; ++rr) { const double v = fabs(work[rr * n2 + c]); if (v > best) { best = v; piv = rr; } }
+        if (piv != c) for (int j = 0; j < n2; ++j) { const double t = work[c * n2 + j]; work[c * n2 + j] = work[piv * n2 + j]; work[piv * n2 + j] = t; }
+        const double d = 1.0 / work[c * n2 + c];
+        for (int j = 0; j < n2; ++j) work[c * n2 + j] *= d;
+        for (int rr = 0; rr < n; ++rr) if (rr != c) {
+            const double f = work[rr * n2 + c];
+            if (f != 0.0) for (int j = 0; j < n2; ++j) work[rr * n2 + j] -= f * work[c * n2 + j];
+        }
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Ainv[i + j * n] = work[i * n2 + n + j];
+}
+__device__ inline void d_chol(int n, const double* A, double* L)
+{
+    for (int e = 0; e < n * n; ++e) L[e] = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double d = A[j + j * n];
+        for (int k = 0; k < j; ++k) d -= L[j + k * n] * L[j + k * n];
+        d = sqrt(d);
+        L[j + j * n] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double v = A[i + j * n];
+            for (int k = 0; k < j; ++k) v -= L[i + k * n] * L[j + k * n];
+            L[i + j * n] = v / d;
+        }
+    }
+}
+__device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
+{
+    const double d1 = 1.0 / sqrt(S[0]);
+    S[0] *= d1 * d1; S[1] *= d1; S[2] *= d1;
+    const double d2 = 1.0 / sqrt(S[3]);
+    S[3] *= d2 * d2; S[1] *= d2; S[2] *= d2;
+    S[0] = 1.0; S[3] = 1.0;
+}
+
+constexpr int TINY_THREADS = 1024;
+constexpr int TINY_WORK = 2 * PMAX * 4 * PMAX + 3 * (2 * PMAX) * (2 * PMAX) + 8 * PMAX;   // scratch doubles for the structural thread
+
+// STEP: 0 = the per-sweep step of single-pass models / CrossQr step 1; 1 = CrossQr step 2 (lambda, sig2t)
+template <int MODEL, int STEP>
+__global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
+{
+    const int J = T.J, p = T.nFeat + 1;
+    const double Nd = (double)T.N;
+    constexpr int NSTAT0 = Stats<MODEL, 0>::NSTAT;
+    const int NG0 = Stats<MODEL, 0>::ng(p);
+    const int NS0 = NSTAT0 * J + NG0;
+    constexpr int NSTAT1 = (MODEL == CROSSQR) ? Stats<CROSSQR, 1>::NSTAT : 0;
+    const int NG1 = (MODEL == CROSSQR) ? 2 : 0;
+    const int NS1 = NSTAT1 * J + NG1;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* st0 = reinterpret_cast<double*>(smem);          // NS0 reduced statistics of slab0
+    double* st1 = st0 + NS0;                                // NS1 reduced statistics of slab1
+    double* part = st1 + NS1;                               // 4 * max(NS0, NS1) partial sums
+    double* work = part + 4 * (NS0 > NS1 ? NS0 : NS1);      // TINY_WORK scratch
+    const int tid = threadIdx.x;
+
+    // ---- fixed-order slab reduction: 4 partial chains per statistic, then their sum
+    {
+        const int part_id = tid >> 8, e0 = tid & 255;
+        for (int e = e0; e < NS0; e += 256) {
+            double t = 0.0;
+            for (int b = part_id; b < T.nb0; b += 4) t += T.slab0[(size_t)b * NS0 + e];
+            part[part_id * NS0 + e] = t;
+        }
+        __syncthreads();
+        for (int e = tid; e < NS0; e += TINY_THREADS) st0[e] = (part[e] + part[NS0 + e]) + (part[2 * NS0 + e] + part[3 * NS0 + e]);
+        __syncthreads();
+        if (MODEL == CROSSQR) {
+            for (int e = e0; e < NS1; e += 256) {
+                double t = 0.0;
+                for (int b = part_id; b < T.nb1; b += 4) t += T.slab1[(size_t)b * NS1 + e];
+                part[part_id * NS1 + e] = t;
+            }
+            __syncthreads();
+            for (int e = tid; e < NS1; e += TINY_THREADS) st1[e] = (part[e] + part[NS1 + e]) + (part[2 * NS1 + e] + part[3 * NS1 + e]);
+            __syncthreads();
+        }
+    }
+
+    const uint32_t prev_row = T.ctl->row;
+    const uint32_t sweep = T.ctl->sweep + ((T.mode == 0 && STEP == 0) ? 1u : 0u);   // the sweep being drawn
+    const uint32_t row = (T.mode == 0 && STEP == 0 && !T.first) ? prev_row + 1u : prev_row;
+
+    // ---- log-likelihood of the sweep the last full pass completed
+    if (STEP == 0 && tid == 0 && !T.first && T.tr_ll) {
+        double llv = st0[NS0 - 1];
+        if (MODEL == CROSSQR) llv += st1[NS1 - 1];
+        T.tr_ll[prev_row] = llv;
+    }
+    if (T.mode == 1) return;
+
+    const double* K0 = T.cst + cst_off_k0(J);
+    const double* cm = T.cst + cst_off_m(J);
+    const double* csq = T.cst + cst_off_csq(J);
+    const double muLam = T.cst[cst_off_mu(J)], sdLam = T.cst[cst_off_mu(J) + 1];
+    const double* XtX = T.cst + cst_off_xtx(J);             // p x p, column-major with leading dimension PMAX
+    double* par = T.par;
+    double* Sigp = par + par_off_sigp(J);
+    double* beta = par + par_off_beta(J);
+
+    // Item statistics S0..: st0[q*J + j]; globals after NSTAT0*J
+    const double* G0 = st0 + NSTAT0 * J;
+
+    // =========================================================== structural draws: thread 0 (wave 0)
+    if (tid == 0 && STEP == 0) {
+        if (MODEL == MLIRT) {
+            // getSubjCoefficientsMlIrt src/Draw.pl.jl:351-357 : beta = (x'x) \ x'theta ; beta[1] = 0 unless intercept
+            double* A = work, *Ai = work + PMAX * PMAX, *w2 = Ai + PMAX * PMAX;
+            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) A[u + v * p] = XtX[u + v * PMAX];
+            d_inverse(p, A, Ai, w2);
+            for (int u = 0; u < p; ++u) { double t = 0.0; for (int v = 0; v < p; ++v) t += Ai[u + v * p] * G0[v]; beta[u] = t; }
+            if (!T.intercept) beta[0] = 0.0;
+        } else if (MODEL == RTIRT) {
+            // drawSubjCoefficients src/Draw.pl.jl:380-393 (precision = 1 .+ kron(inv(Sigp), x'x): +1 on EVERY element)
+            const int n = 2 * p;
+            double* P = work, *V = P + n * n, *L = V + n * n, *w2 = L + n * n;   // w2: n*2n
+            double* tv = w2 + 2 * n * n, *pm = tv + n, *z = pm + n;
+            const double* xt = G0, *xz = G0 + p;
+            const double tt = G0[2 * p], tz = G0[2 * p + 1], zz = G0[2 * p + 2];
+            double iO[4];
+            { const double det = Sigp[0] * Sigp[3] - Sigp[1] * Sigp[2]; iO[0] = Sigp[3] / det; iO[1] = -Sigp[1] / det; iO[2] = -Sigp[2] / det; iO[3] = Sigp[0] / det; }
+            for (int i1 = 0; i1 < 2; ++i1) for (int j1 = 0; j1 < 2; ++j1)
+                for (int i2 = 0; i2 < p; ++i2) for (int j2 = 0; j2 < p; ++j2)
+                    P[(i1 * p + i2) + (j1 * p + j2) * n] = 1.0 + iO[i1 + j1 * 2] * XtX[i2 + j2 * PMAX];
+            d_inverse(n, P, V, w2);
+            for (int cc = 0; cc < 2; ++cc) for (int rr = 0; rr < p; ++rr) tv[cc * p + rr] = 0.0 + xt[rr] * iO[cc] + xz[rr] * iO[cc + 2];
+            for (int i = 0; i < n; ++i) { double t = 0.0; for (int j = 0; j < n; ++j) t += V[i + j * n] * tv[j]; pm[i] = t; }
+            for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) V[i + j * n] = V[j + i * n];   // Symmetric(parV): upper triangle
+            d_chol(n, V, L);
+            Stream sb(T.seed, T.chain, SITE_BETA, 0u, 0u, sweep);
+            for (int i = 0; i < n; ++i) z[i] = normal<double>(sb);
+            double bnew[2 * PMAX];
+            for (int i = 0; i < n; ++i) { double t = pm[i]; for (int j = 0; j <= i; ++j) t += L[i + j * n] * z[j]; bnew[i] = t; }
+            if (!T.intercept) { bnew[0] = 0.0; bnew[p] = 0.0; }
+            for (int u = 0; u < p; ++u) { beta[u] = bnew[u]; beta[PMAX + u] = bnew[p + u]; }
+            // drawSubjCovariance src/Draw.pl.jl:499-515 : InverseWishart(N+3, e'e + I)
+            double bAb[4] = {0, 0, 0, 0}, bx[4];
+            for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) {
+                double t = 0.0;
+                for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) t += bnew[a_ * p + u] * XtX[u + v * PMAX] * bnew[b_ * p + v];
+                bAb[a_ + 2 * b_] = t;
+            }
+            // bx[a,b] = beta_a' x'eta_b
+            for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) {
+                double t = 0.0; const double* xe = b_ == 0 ? xt : xz;
+                for (int u = 0; u < p; ++u) t += bnew[a_ * p + u] * xe[u];
+                bx[a_ + 2 * b_] = t;
+            }
+            const double ee00 = tt - 2.0 * bx[0] + bAb[0];
+            const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
+            const double ee11 = zz - 2.0 * bx[3] + bAb[3];
+            const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
+            double Pi[4]; { const double det = Psi[0] * Psi[3] - Psi[1] * Psi[2]; Pi[0] = Psi[3] / det; Pi[1] = -Psi[1] / det; Pi[2] = -Psi[2] / det; Pi[3] = Psi[0] / det; }
+            const double l00 = sqrt(Pi[0]), l10 = Pi[1] / l00, l11 = sqrt(Pi[3] - l10 * l10);
+            const double df = Nd + 3.0;
+            Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
+            const double c1 = sqrt(chisq(ss, df));
+            const double n21 = normal<double>(ss);
+            const double c2 = sqrt(chisq(ss, df - 1.0));
+            const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
+            const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
+            const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
+            double S[4] = { Wm[3] / det, -Wm[1] / det, -Wm[2] / det, Wm[0] / det };
+            if (T.cov2one) d_cov2one(S);
+            for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+        } else if (MODEL == LATENTQR) {
+            // getSubjCoefficientsLatentQr src/Draw.pl.jl:446-458 : beta = (x'x)^-1 x'(zeta - k1 nu), x = [1 X theta]
+            const int q = p + 1;
+            const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
+            const double tu = G0[2 * p + 1], uu = G0[2 * p + 2], snu = G0[2 * p + 3], snu2 = G0[2 * p + 4];
+            double* A = work, *Ai = A + PMAX * PMAX, *w2 = Ai + PMAX * PMAX, *rhs = w2 + 2 * PMAX * PMAX;
+            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) A[u + v * q] = XtX[u + v * PMAX];
+            for (int u = 0; u < p; ++u) { A[u + p * q] = xt[u]; A[p + u * q] = xt[u]; rhs[u] = xu[u]; }
+            A[p + p * q] = tt; rhs[p] = tu;
+            d_inverse(q, A, Ai, w2);
+            double bnew[PMAX];
+            for (int u = 0; u < q; ++u) { double t = 0.0; for (int v = 0; v < q; ++v) t += Ai[u + v * q] * rhs[v]; bnew[u] = t; }
+            if (!T.intercept) bnew[0] = 0.0;
+            for (int u = 0; u < q; ++u) beta[u] = bnew[u];
+            // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
+            double sr2 = uu;
+            for (int u = 0; u < q; ++u) sr2 -= 2.0 * bnew[u] * rhs[u];
+            for (int u = 0; u < q; ++u) for (int v = 0; v < q; ++v) sr2 += bnew[u] * A[u + v * q] * bnew[v];
+            const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
+            const double parB = 1e-3 + sr2 * sw / sw2 + snu;
+            Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
+            const double v = invgamma(ss, 1e-3 + Nd * 3.0 / 2.0, parB);
+            double S[4] = { 1.0, 0.0, 0.0, v };
+            if (T.cov2one) d_cov2one(S);
+            for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+        } else if (MODEL == CROSSQR) {
+            // drawSubjCovarianceCross src/Draw.pl.jl:542-557
+            const double zz = st1[NSTAT1 * J + 0];
+            Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
+            const double v = invgamma(ss, 1e-3 + Nd / 2.0, 1e-3 + zz / 2.0);
+            double S[4] = { 1.0, 0.0, 0.0, v };
+            if (T.cov2one) d_cov2one(S);
+            for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+        }
+    }
+
+    // =========================================================== item draws: one thread per item, in waves 1..
+    const int j = tid - 64;
+    if (j >= 0 && j < J) {
+        if (STEP == 0) {
+            const double S0 = st0[0 * J + j], S1 = st0[1 * J + j], S2 = st0[2 * J + j], K1 = st0[3 * J + j];
+            double a = par[j], b = par[J + j];
+            if (MODEL == CROSSQR) {
+                // rho_t: drawSubjCorrCrossQr src/Draw.pl.jl:474-489 (uses sig2t_{t-1})
+                const double sg = par[3 * J + j];
+                const double R0 = st1[0 * J + j], R1 = st1[1 * J + j];
+                const double parV = 1.0 / (1.0 + R0 / (sg * T.k2));
+                const double parM = parV * (0.0 + R1 / (sg * T.k2));
+                Stream sr(T.seed, T.chain, SITE_RHO, 0u, (uint32_t)j, sweep);
+                par[4 * J + j] = parM + sqrt(parV) * normal<double>(sr);
+            }
+            auto draw_b = [&]() {   // drawItemDifficulty src/Draw.pl.jl:98-105
+                const double parV = 1.0 / (1.0 + a * a * S0);
+                const double parM = parV * (0.0 - (a * K0[j] - a * a * S1));
+                Stream sb(T.seed, T.chain, SITE_B, 0u, (uint32_t)j, sweep);
+                double v = parM + sqrt(parV) * normal<double>(sb);
+                b = v < -4.0 ? -4.0 : (v > 4.0 ? 4.0 : v);
+            };
+            auto draw_a = [&]() {   // drawItemDiscrimination src/Draw.pl.jl:88-93
+                const double parV = 1.0 / (1.0 + (S2 - 2.0 * b * S1 + b * b * S0));
+                const double parM = parV * (1.0 + (K1 - b * K0[j]));
+                Stream sa(T.seed, T.chain, SITE_A, 0u, (uint32_t)j, sweep);
+                a = truncnorm0(sa, parM, sqrt(parV));
+                if (T.onepl) a = 1.0;
+            };
+            if (MODEL == MLIRT) { draw_a(); draw_b(); }   // src/GibbsRtIrt.pl.jl:233-237
+            else { draw_b(); draw_a(); }                  // :301-305
+            par[j] = a; par[J + j] = b;
+        }
+        if ((MODEL == RTIRT || MODEL == LATENTQR) && STEP == 0) {
+            // lambda: drawItemIntensity src/Draw.pl.jl:215-220 ; sig2t: drawItemTimeResidual :257-262
+            // sum zeta, sum zeta^2 over subjects (RtIrt: (x'zeta)[0] and zz; LatentQr: tracked explicitly)
+            const double sz = (MODEL == RTIRT) ? G0[p] : G0[2 * p + 5];
+            const double zz = (MODEL == RTIRT) ? G0[2 * p + 2] : G0[2 * p + 6];
+            const double Gj = st0[4 * J + j];
+            const double sg_old = par[3 * J + j];
+            const double parV = 1.0 / (1.0 / (sdLam * sdLam) + Nd / sg_old);
+            const double parM = parV * (muLam / (sdLam * sdLam) + (Nd * cm[j] + sz) / sg_old);
+            Stream sl(T.seed, T.chain, SITE_LAMBDA, 0u, (uint32_t)j, sweep);
+            const double lam = truncnorm0(sl, parM, sqrt(parV));
+            const double lc = lam - cm[j];
+            const double ssq = csq[j] + 2.0 * Gj + zz - 2.0 * lc * sz + Nd * lc * lc;
+            Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
+            const double sg = invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq / 2.0);
+            par[2 * J + j] = lam; par[3 * J + j] = sg;
+        }
+        if (MODEL == CROSSQR && STEP == 1) {
+            // lambda: drawItemIntensityCrossQr src/Draw.pl.jl:239-251 ; sig2t: drawItemTimeResidualCrossQr :278-288
+            const double W0 = st0[4 * J + j], W1 = st0[5 * J + j], W2 = st0[6 * J + j], V = st0[7 * J + j];
+            const double sg_old = par[3 * J + j];
+            const double parV = 1.0 / (1.0 / (sdLam * sdLam) + W0 / (sg_old * T.k2));
+            const double parM = parV * (muLam / (sdLam * sdLam) + (W1 + cm[j] * W0) / (sg_old * T.k2));
+            Stream sl(T.seed, T.chain, SITE_LAMBDA, 0u, (uint32_t)j, sweep);
+            const double lam = truncnorm0(sl, parM, sqrt(parV));
+            const double lc = lam - cm[j];
+            const double ssq = (W2 - 2.0 * lc * W1 + lc * lc * W0) / (2.0 * T.k2);
+            Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
+            const double sg = invgamma(sv, 1e-3 + Nd * 3.0 / 2.0, 1e-3 + ssq + V);
+            par[2 * J + j] = lam; par[3 * J + j] = sg;
+        }
+    }
+    __syncthreads();
+
+    // =========================================================== bookkeeping + item trace
+    const bool last_step = (MODEL != CROSSQR) || STEP == 1;
+    if (last_step && T.tr_item) {
+        const int wrow = 4 * J + T.nq;
+        double* tr = T.tr_item + (size_t)row * wrow;
+        for (int e = tid; e < 4 * J; e += TINY_THREADS) tr[e] = par[e];
+        if (tid < T.nq) {
+            double v;
+            if (MODEL == MLIRT) v = beta[tid];
+            else if (MODEL == RTIRT) { const int nb = 2 * p; v = tid < nb ? (tid < p ? beta[tid] : beta[PMAX + tid - p]) : Sigp[tid - nb]; }
+            else if (MODEL == CROSSQR) v = tid < J ? par[4 * J + tid] : Sigp[tid - J];
+            else { const int nb = p + 1; v = tid < nb ? beta[tid] : Sigp[tid - nb]; }
+            tr[4 * J + tid] = v;
+        }
+    }
+    if (tid == 0) {
+        bool bad = false;
+        for (int e = 0; e < 4 * J; ++e) bad |= !(fabs(par[e]) < 1e300);
+        if (bad) T.ctl->err = 1u;
+        if (STEP == 0) { T.ctl->sweep = sweep; T.ctl->row = row; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// unit kernels for parity tests of the device samplers against the oracle
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename real>
+__global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uint32_t sweep, long long n,
+                                    const double* par0, const double* par1, double* out)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Stream st(seed, 0u, site, (uint32_t)k, 0u, sweep);
+    double v = 0.0;
+    switch (which) {
+    case 0: v = (double)uniform<real>(st); break;
+    case 1: v = (double)normal<real>(st); break;
+    case 2: v = (double)expo<real>(st); break;
+    case 3: v = (double)pg1<real>(st, (real)par0[k]); break;
+    case 4: v = (double)invgauss<real>(st, (real)par0[k], (real)par1[k]); break;
+    case 5: v = truncnorm0(st, par0[k], par1[k]); break;
+    case 6: v = gamma_mt(st, par0[k]); break;
+    case 7: v = (double)pg_mass_texpon<real>((real)par0[k]); break;
+    case 8: v = (double)qr_weight<real>(st, (real)par0[k], (real)par1[k]); break;
+    }
+    out[k] = v;
+}
+
+}  // namespace erm

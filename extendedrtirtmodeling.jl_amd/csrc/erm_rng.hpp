@@ -1,0 +1,238 @@
+// erm_rng.hpp -- device-side counter-based streams and scalar samplers (gfx950).
+//
+// Sampling specification (shared with the CPU oracle, which restates it independently in C):
+//   stream(site, i, j, sweep) = words of Philox4x32-10(key = seed; ctr = {i, j, sweep, site<<24 | chain<<16 | k}),
+//   k = 0,1,2,..., consumed strictly in order.  Because draws are addressed by (site, i, j, sweep) and not by
+//   thread id, results do not depend on launch geometry.
+//   uniform: fp64 (x + 1/2) 2^-32; fp32 ((x >> 8) + 1/2) 2^-24 (the same value rounded to 24 bits)
+//   expo   : -log(u);  normal: sqrt(-2 log u1) cos(2 pi u2) (two words per variate)
+//   PG(1,c): Polson-Scott-Windle / Devroye alternating-series sampler, t = 0.64
+//            (replaces PolyaGammaPSWSampler(1, eta) at /root/reference/src/Draw.pl.jl:38)
+//   IG     : Michael-Schucany-Haas (replaces Distributions.InverseGaussian at src/Draw.pl.jl:312,335)
+//   TN, Gamma (fp64 only; item-level draws): Robert (1995) / Marsaglia-Tsang (2000)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace erm {
+
+enum Site : uint32_t {
+    SITE_OMEGA = 1, SITE_THETA = 2, SITE_ZETA = 3, SITE_NU = 4, SITE_B = 5, SITE_A = 6,
+    SITE_LAMBDA = 7, SITE_SIG2T = 8, SITE_BETA = 9, SITE_SIGP = 10, SITE_RHO = 11, SITE_TEST = 15
+};
+
+// ---- precision-generic math wrappers -------------------------------------------------------
+__device__ __forceinline__ float  r_exp(float x)  { return __expf(x); }
+__device__ __forceinline__ double r_exp(double x) { return exp(x); }
+__device__ __forceinline__ float  r_log(float x)  { return __logf(x); }
+__device__ __forceinline__ double r_log(double x) { return log(x); }
+__device__ __forceinline__ float  r_sqrt(float x)  { return __fsqrt_rn(x); }
+__device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float  r_rcp(float x)  { return __frcp_rn(x); }
+__device__ __forceinline__ double r_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float  r_abs(float x)  { return fabsf(x); }
+__device__ __forceinline__ double r_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float  r_cospi(float x)  { return cospif(x); }
+__device__ __forceinline__ double r_cospi(double x) { return cospi(x); }
+__device__ __forceinline__ float  r_erfc(float x)  { return erfcf(x); }
+__device__ __forceinline__ double r_erfc(double x) { return erfc(x); }
+__device__ __forceinline__ float  r_log1p(float x)  { return log1pf(x); }
+__device__ __forceinline__ double r_log1p(double x) { return log1p(x); }
+
+template <typename real> struct Const;
+template <> struct Const<float> {
+    static constexpr float PI = 3.14159265358979323846f;
+    static constexpr float SQRT1_2 = 0.70710678118654752440f;
+};
+template <> struct Const<double> {
+    static constexpr double PI = 3.14159265358979323846;
+    static constexpr double SQRT1_2 = 0.70710678118654752440;
+};
+
+// ---- Philox4x32-10 --------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+struct Stream {
+    uint32_t k0, k1, c0, c1, c2, c3;   // c3 holds site/chain in the top 16 bits, block index below
+    uint32_t b0, b1, b2, b3;
+    int n;                               // unread words
+    __device__ __forceinline__ Stream(uint64_t seed, uint32_t chain, uint32_t site, uint32_t i, uint32_t j, uint32_t sweep)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), c0(i), c1(j), c2(sweep),
+          c3((site << 24) | ((chain & 0xFFu) << 16)), b0(0), b1(0), b2(0), b3(0), n(0) {}
+    __device__ __forceinline__ uint32_t next()
+    {
+        if (n == 0) {
+            philox4x32_10(c0, c1, c2, c3, k0, k1, b0, b1, b2, b3);
+            c3 = (c3 & 0xFFFF0000u) | ((c3 + 1u) & 0xFFFFu);
+            n = 4;
+        }
+        const uint32_t v = b0;
+        b0 = b1; b1 = b2; b2 = b3;
+        --n;
+        return v;
+    }
+};
+
+template <typename real> __device__ __forceinline__ real uniform(Stream& s);
+template <> __device__ __forceinline__ double uniform<double>(Stream& s) { return ((double)s.next() + 0.5) * (1.0 / 4294967296.0); }
+template <> __device__ __forceinline__ float uniform<float>(Stream& s) { return ((float)(s.next() >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+template <typename real> __device__ __forceinline__ real expo(Stream& s) { return -r_log(uniform<real>(s)); }
+
+template <typename real> __device__ __forceinline__ real normal(Stream& s)
+{
+    const real u1 = uniform<real>(s), u2 = uniform<real>(s);
+    return r_sqrt(real(-2) * r_log(u1)) * r_cospi(real(2) * u2);
+}
+
+// log Phi(x), stable in both tails
+template <typename real> __device__ __forceinline__ real log_pnorm(real x)
+{
+    if (x > real(0)) return r_log1p(real(-0.5) * r_erfc(x * Const<real>::SQRT1_2));
+    return r_log(real(0.5) * r_erfc(-x * Const<real>::SQRT1_2));
+}
+
+// IG(mu, lambda), Michael-Schucany-Haas with the cancellation-free smaller root
+template <typename real> __device__ __forceinline__ real invgauss(Stream& s, real mu, real lambda)
+{
+    const real nrm = normal<real>(s);
+    const real w = mu * nrm * nrm;
+    const real sq = r_sqrt(w) * r_sqrt(real(4) * lambda + w);
+    const real q = real(2) * r_sqrt(lambda * w) / (sq + w);
+    const real x1 = mu * q * q;
+    const real u = uniform<real>(s);
+    return (u >= mu / (mu + x1)) ? mu * mu / x1 : x1;
+}
+
+// nu = clamp(1 / IG(clamp(parB/parA, 1e-10, Inf), parB^2), 1e-10, 1e10): src/Draw.pl.jl:310-318, 333-341
+template <typename real> __device__ __forceinline__ real qr_weight(Stream& s, real parA, real parB)
+{
+    real mu = parB / parA;
+    mu = mu < real(1e-10) ? real(1e-10) : mu;
+    real nu = real(1) / invgauss<real>(s, mu, parB * parB);
+    nu = nu < real(1e-10) ? real(1e-10) : (nu > real(1e10) ? real(1e10) : nu);
+    return nu;
+}
+
+// ---- Polya-Gamma PG(1, c) -------------------------------------------------------------------
+template <typename real> __device__ __forceinline__ real pg_an(int n, real x)
+{
+    const real t = real(0.64);
+    const real kk = (real(n) + real(0.5)) * Const<real>::PI;
+    if (x > t) return kk * r_exp(real(-0.5) * kk * kk * x);
+    const real h = real(2) / (Const<real>::PI * x);
+    const real nh = real(n) + real(0.5);
+    return kk * h * r_sqrt(h) * r_exp(real(-2) * nh * nh / x);
+}
+
+template <typename real> __device__ __forceinline__ real pg_mass_texpon(real z)
+{
+    const real t = real(0.64);
+    const real PI = Const<real>::PI;
+    const real fz = real(0.125) * PI * PI + real(0.5) * z * z;
+    const real rt = r_sqrt(real(1) / t);
+    const real b = rt * (t * z - real(1));
+    const real a = -rt * (t * z + real(1));
+    const real x0 = r_log(fz) + fz * t;
+    const real xb = x0 - z + log_pnorm<real>(b);
+    const real xa = x0 + z + log_pnorm<real>(a);
+    const real qdivp = real(4) / PI * (r_exp(xb) + r_exp(xa));
+    return real(1) / (real(1) + qdivp);
+}
+
+template <typename real> __device__ __forceinline__ real pg_rtigauss(Stream& s, real z)
+{
+    const real t = real(0.64);
+    real x;
+    if (z < real(1) / t) {
+        real alpha;
+        do {
+            real e1, e2;
+            do { e1 = expo<real>(s); e2 = expo<real>(s); } while (e1 * e1 > real(2) * e2 / t);
+            x = real(1) + e1 * t;
+            x = t / (x * x);
+            alpha = r_exp(real(-0.5) * z * z * x);
+        } while (uniform<real>(s) > alpha);
+    } else {
+        const real mu = real(1) / z;
+        do { x = invgauss<real>(s, mu, real(1)); } while (x > t);
+    }
+    return x;
+}
+
+template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c)
+{
+    const real t = real(0.64);
+    const real PI = Const<real>::PI;
+    const real z = real(0.5) * r_abs(c);
+    const real fz = real(0.125) * PI * PI + real(0.5) * z * z;
+    const real r = pg_mass_texpon<real>(z);
+    for (;;) {
+        real x;
+        if (uniform<real>(s) < r) x = t + expo<real>(s) / fz;
+        else x = pg_rtigauss<real>(s, z);
+        real S = pg_an<real>(0, x);
+        const real y = uniform<real>(s) * S;
+        int n = 0;
+        for (;;) {
+            ++n;
+            if (n & 1) { S -= pg_an<real>(n, x); if (y <= S) return real(0.25) * x; }
+            else       { S += pg_an<real>(n, x); if (y > S) break; }
+            if (n > 200) return real(0.25) * x;
+        }
+    }
+}
+
+// ---- item-level samplers (fp64 only) --------------------------------------------------------
+__device__ __forceinline__ double truncnorm0(Stream& s, double m, double sd)
+{
+    const double alpha = -m / sd;
+    double z;
+    if (alpha <= 0.0) {
+        do { z = normal<double>(s); } while (z < alpha);
+    } else {
+        const double lam = 0.5 * (alpha + sqrt(alpha * alpha + 4.0));
+        for (;;) {
+            z = alpha + expo<double>(s) / lam;
+            const double u = uniform<double>(s);
+            if (u <= exp(-0.5 * (z - lam) * (z - lam))) break;
+        }
+    }
+    return m + sd * z;
+}
+
+__device__ __forceinline__ double gamma_mt(Stream& s, double shape)
+{
+    const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x, v;
+        do { x = normal<double>(s); v = 1.0 + c * x; } while (v <= 0.0);
+        v = v * v * v;
+        const double u = uniform<double>(s);
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+    }
+}
+__device__ __forceinline__ double invgamma(Stream& s, double shape, double scale) { return scale / gamma_mt(s, shape); }
+__device__ __forceinline__ double chisq(Stream& s, double k) { return 2.0 * gamma_mt(s, 0.5 * k); }
+
+}  // namespace erm

@@ -1,0 +1,674 @@
+// ertirt.hip -- C-ABI host implementation of libertirt.so (declared in include/ertirt.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I include ertirt.hip -o libertirt.so
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+#include "ertirt.h"
+#include "erm_kernels.hpp"
+
+using namespace erm;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            return fail(ERM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                \
+        }                                                                                                \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        if (n == 0) return 0;
+        HIPCHK(hipMalloc(&p, n));
+        HIPCHK(hipMemset(p, 0, n));
+        return 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct EngineBase {
+    erm_config cfg{};
+    virtual ~EngineBase() {}
+    virtual int init() = 0;
+    virtual int set_data(const uint8_t*, const double*, const double*) = 0;
+    virtual int set_state(const erm_state*) = 0;
+    virtual int get_state(erm_state*) = 0;
+    virtual int run(int64_t) = 0;
+    virtual int get_trace(int, double*) = 0;
+    virtual int get_item_trace(double*) = 0;
+    virtual int get_mean(erm_state*) = 0;
+    virtual int reset_trace() = 0;
+    int64_t rows_done = 0;
+    int64_t post_rows = 0;
+    erm_timing timing{};
+    int64_t trace_width(int which) const {
+        const int64_t N = cfg.n_subj, J = cfg.n_item, F = cfg.n_feat;
+        switch (which) {
+        case ERM_TRACE_RA: return N + 2 * J;                                              // src/GibbsRtIrt.pl.jl:44,65
+        case ERM_TRACE_RT: return cfg.model == ERM_MODEL_MLIRT ? 0 : N + 2 * J;           // :66 (MlIrt's rt stays [])
+        case ERM_TRACE_QR:
+            switch (cfg.model) {
+            case ERM_MODEL_MLIRT: return F + 1;                                           // :45
+            case ERM_MODEL_RTIRT: return 2 * (F + 1) + 4;                                 // :67
+            case ERM_MODEL_CROSSQR: return J + 4 + N * J;                                 // src/GibbsRtIrtCross.pl.jl:65
+            case ERM_MODEL_LATENTQR: return F + 2 + 4 + N;                                // src/GibbsRtIrtLatent.pl.jl:60
+            }
+            return 0;
+        case ERM_TRACE_LOGLIKE: return 1;
+        }
+        return 0;
+    }
+    int nq() const {
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: return cfg.n_feat + 1;
+        case ERM_MODEL_RTIRT: return 2 * (cfg.n_feat + 1) + 4;
+        case ERM_MODEL_CROSSQR: return cfg.n_item + 4;
+        default: return cfg.n_feat + 2 + 4;
+        }
+    }
+    int64_t item_trace_width() const { return 4 * (int64_t)cfg.n_item + nq(); }
+};
+
+template <typename real> struct Engine : EngineBase {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> pass_ev;
+    int cu_count = 256;
+    int64_t N = 0; int J = 0, F = 0, Fk = 0;   // Fk = covariate columns the kernels see (0 for CrossQr)
+    int64_t rows_cap = 0;
+    bool has_data = false;
+    int W = 8, logW = 3, IPL = 1, block_threads = 1024, grid_blocks = 256;
+    size_t lds_pass[2] = {0, 0};
+    int ns[2] = {0, 0};
+    uint32_t sweeps_total = 0;
+
+    DevBuf dY, dC, dOmega, dNu, dX, dTheta, dZeta, dPar, dCst, dSlab0, dSlab1, dCtl;
+    DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
+
+    ~Engine() override {
+        for (auto e : pass_ev) (void)hipEventDestroy(e);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    bool is_rt() const { return cfg.model != ERM_MODEL_MLIRT; }
+    int p() const { return Fk + 1; }
+    int stat_sizes(int phase) const {
+        const int pp = p();
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: return Stats<MLIRT, 0>::NSTAT * J + Stats<MLIRT, 0>::ng(pp);
+        case ERM_MODEL_RTIRT: return Stats<RTIRT, 0>::NSTAT * J + Stats<RTIRT, 0>::ng(pp);
+        case ERM_MODEL_LATENTQR: return Stats<LATENTQR, 0>::NSTAT * J + Stats<LATENTQR, 0>::ng(pp);
+        default: return phase == 0 ? Stats<CROSSQR, 0>::NSTAT * J + 1 : Stats<CROSSQR, 1>::NSTAT * J + 2;
+        }
+    }
+    int nstat(int phase) const {
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: return 4;
+        case ERM_MODEL_RTIRT: return 5;
+        case ERM_MODEL_LATENTQR: return 5;
+        default: return phase == 0 ? 8 : 2;
+        }
+    }
+    size_t pass_lds(int phase, int nWaves) const {
+        const int R = 64 / W;
+        const int ng = stat_sizes(phase) - nstat(phase) * J;
+        size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * ((size_t)nstat(phase) * J + (size_t)ng * R + 1);
+        return d * sizeof(double) + (size_t)NITEMARR * J * sizeof(real);
+    }
+
+    int init() override {
+        N = cfg.n_subj; J = cfg.n_item; F = cfg.n_feat;
+        Fk = (cfg.model == ERM_MODEL_CROSSQR) ? 0 : F;
+        if (N <= 0 || J <= 0 || F < 0) return fail(ERM_ERR_ARG, "n_subj, n_item must be positive and n_feat non-negative");
+        if (N >= (1LL << 32)) return fail(ERM_ERR_ARG, "n_subj must fit 32 bits");
+        if (cfg.model < 0 || cfg.model > 3) return fail(ERM_ERR_ARG, "unknown model");
+        if (Fk + 2 > PMAX) return fail(ERM_ERR_ARG, "n_feat too large (max " + std::to_string(PMAX - 2) + ")");
+        if (J > 896) return fail(ERM_ERR_ARG, "n_item too large (max 896)");
+        if ((cfg.model == ERM_MODEL_CROSSQR || cfg.model == ERM_MODEL_LATENTQR) && !(cfg.q_rt > 0.0 && cfg.q_rt < 1.0))
+            return fail(ERM_ERR_ARG, "qRt must be between 0 and 1");   // @assert at src/Draw.pl.jl:476
+        if (cfg.n_iter < 0 || cfg.n_chain < 1 || cfg.n_burnin < 0) return fail(ERM_ERR_ARG, "bad n_iter / n_chain / n_burnin");
+        if (cfg.sigp_mode != 0) return fail(ERM_ERR_ARG, "sigp_mode 1 is reserved");
+        HIPCHK(hipSetDevice(cfg.device));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
+        cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&ev0));
+        HIPCHK(hipEventCreate(&ev1));
+
+        // ---- geometry: W lanes per subject
+        if (cfg.lanes_per_row > 0) {
+            W = cfg.lanes_per_row;
+            if (W > 64 || (W & (W - 1))) return fail(ERM_ERR_ARG, "lanes_per_row must be a power of two <= 64");
+        } else {
+            // smallest padding waste first, then enough lanes to fill the chip (>= 4 waves per SIMD), then larger W
+            double best = 1e30; W = 8;
+            for (int w = 4; w <= 64; w <<= 1) {
+                const int ipl = (J + w - 1) / w;
+                double waste = (double)(w * ipl) / J;
+                const double lanes = (double)N * w;
+                if (lanes < 64.0 * 16 * cu_count) waste *= 1.0 + 0.25 * std::log2(64.0 * 16 * cu_count / lanes);
+                waste *= 1.0 + 0.6 / ipl;     // per-row work is amortised over ipl cell iterations
+                if (waste < best - 1e-12) { best = waste; W = w; }
+            }
+        }
+        logW = 0; while ((1 << logW) < W) ++logW;
+        IPL = (J + W - 1) / W;
+        block_threads = cfg.block_threads > 0 ? cfg.block_threads : 1024;
+        if (block_threads % 64 || block_threads > 1024) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= 1024");
+        const int R = 64 / W;
+        const int64_t nGroups = (N + R - 1) / R;
+        const int nWaves = block_threads / 64;
+        const int64_t need = (nGroups + nWaves - 1) / nWaves;
+        const int per_cu = std::max(1, 16 / nWaves);
+        grid_blocks = cfg.grid_blocks > 0 ? cfg.grid_blocks : (int)std::min<int64_t>(need, (int64_t)cu_count * per_cu);
+        if (grid_blocks < 1) grid_blocks = 1;
+        for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
+        if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads");
+
+        // ---- device memory
+        rows_cap = (int64_t)cfg.n_iter * cfg.n_chain;
+        const size_t NJ = (size_t)N * J;
+        int rc = 0;
+        rc |= dY.alloc(NJ);
+        rc |= dOmega.alloc(NJ * sizeof(real));
+        if (is_rt()) rc |= dC.alloc(NJ * sizeof(real));
+        if (cfg.model == ERM_MODEL_CROSSQR) rc |= dNu.alloc(NJ * sizeof(real));
+        if (cfg.model == ERM_MODEL_LATENTQR) rc |= dNu.alloc((size_t)N * sizeof(real));
+        if (Fk > 0) rc |= dX.alloc((size_t)N * Fk * sizeof(real));
+        rc |= dTheta.alloc((size_t)N * sizeof(real));
+        rc |= dZeta.alloc((size_t)N * sizeof(real));
+        rc |= dPar.alloc((size_t)par_size(J) * sizeof(double));
+        rc |= dCst.alloc((size_t)cst_size(J) * sizeof(double));
+        rc |= dSlab0.alloc((size_t)grid_blocks * ns[0] * sizeof(double));
+        if (cfg.model == ERM_MODEL_CROSSQR) rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double));
+        rc |= dCtl.alloc(sizeof(Ctl));
+        rc |= dSumTheta.alloc((size_t)N * sizeof(double));
+        rc |= dSumZeta.alloc((size_t)N * sizeof(double));
+        if (cfg.model == ERM_MODEL_CROSSQR) rc |= dSumNu.alloc(NJ * sizeof(double));
+        if (cfg.model == ERM_MODEL_LATENTQR) rc |= dSumNu.alloc((size_t)N * sizeof(double));
+        rc |= dTrItem.alloc((size_t)std::max<int64_t>(rows_cap, 1) * item_trace_width() * sizeof(double));
+        rc |= dTrLl.alloc((size_t)std::max<int64_t>(rows_cap, 1) * sizeof(double));
+        if (cfg.trace_mode == ERM_TRACE_FULL && rows_cap > 0) {
+            rc |= dTrTheta.alloc((size_t)rows_cap * N * sizeof(real));
+            if (is_rt()) rc |= dTrZeta.alloc((size_t)rows_cap * N * sizeof(real));
+            if (cfg.model == ERM_MODEL_LATENTQR) rc |= dTrNu.alloc((size_t)rows_cap * N * sizeof(real));
+        }
+        if (rc) return rc;
+        if (cfg.profile) {
+            pass_ev.resize(2 * 4096);
+            for (auto& e : pass_ev) HIPCHK(hipEventCreate(&e));
+        }
+
+        // ---- default state (constructors' deterministic part: a = 1, b = 0, lambda = 0, sig2t = 1, Sigp = I)
+        std::vector<double> par(par_size(J), 0.0);
+        for (int j = 0; j < J; ++j) { par[j] = 1.0; par[3 * J + j] = 1.0; }
+        par[par_off_sigp(J) + 0] = 1.0; par[par_off_sigp(J) + 3] = 1.0;
+        HIPCHK(hipMemcpy(dPar.p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (dNu.p) {
+            std::vector<real> ones(dNu.bytes / sizeof(real), real(1));
+            HIPCHK(hipMemcpy(dNu.p, ones.data(), dNu.bytes, hipMemcpyHostToDevice));
+        }
+        timing.lanes_per_row = W; timing.block_threads = block_threads; timing.grid_blocks = grid_blocks;
+        timing.lds_bytes = (int32_t)std::max(lds_pass[0], lds_pass[1]); timing.cu_count = cu_count;
+        return configure_kernels();
+    }
+
+    // -------------------------------------------------------------------------------------------- kernels
+    template <int MODEL, int PHASE> int set_lds_attr(size_t bytes) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<MODEL, real, PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        return 0;
+    }
+    size_t tiny_lds() const {
+        const int mx = std::max(ns[0], ns[1]);
+        return (size_t)(ns[0] + (cfg.model == ERM_MODEL_CROSSQR ? ns[1] : 0) + 4 * mx + TINY_WORK) * sizeof(double);
+    }
+    int configure_kernels() {
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: if (int rc = set_lds_attr<MLIRT, 0>(lds_pass[0])) return rc; break;
+        case ERM_MODEL_RTIRT: if (int rc = set_lds_attr<RTIRT, 0>(lds_pass[0])) return rc; break;
+        case ERM_MODEL_LATENTQR: if (int rc = set_lds_attr<LATENTQR, 0>(lds_pass[0])) return rc; break;
+        default:
+            if (int rc = set_lds_attr<CROSSQR, 0>(lds_pass[0])) return rc;
+            if (int rc = set_lds_attr<CROSSQR, 1>(lds_pass[1])) return rc;
+        }
+        const int tl = (int)tiny_lds();
+        if (tl > 160 * 1024) return fail(ERM_ERR_ARG, "tiny-step LDS footprint too large");
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<MLIRT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl)); break;
+        case ERM_MODEL_RTIRT: HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<RTIRT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl)); break;
+        case ERM_MODEL_LATENTQR: HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<LATENTQR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl)); break;
+        default:
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<CROSSQR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<CROSSQR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
+        }
+        return 0;
+    }
+
+    PassArgs<real> pass_args(int phase, int mode) const {
+        PassArgs<real> a{};
+        a.Y = dY.as<uint8_t>(); a.C = dC.as<real>(); a.omega = dOmega.as<real>(); a.nu = dNu.as<real>(); a.X = dX.as<real>();
+        a.theta = dTheta.as<real>(); a.zeta = dZeta.as<real>();
+        a.par = dPar.as<double>(); a.cst = dCst.as<double>();
+        a.slab = phase == 0 ? dSlab0.as<double>() : dSlab1.as<double>();
+        a.ctl = dCtl.as<Ctl>();
+        a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
+        a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
+        a.N = N; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode;
+        a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
+        const double q = cfg.q_rt;
+        a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
+        return a;
+    }
+    TinyArgs tiny_args(int mode, int first) const {
+        TinyArgs t{};
+        t.par = dPar.as<double>(); t.cst = dCst.as<double>(); t.slab0 = dSlab0.as<double>(); t.slab1 = dSlab1.as<double>();
+        t.ctl = dCtl.as<Ctl>(); t.tr_item = dTrItem.as<double>(); t.tr_ll = dTrLl.as<double>();
+        t.N = N; t.J = J; t.nFeat = Fk; t.nb0 = grid_blocks; t.nb1 = grid_blocks; t.mode = mode; t.first = first;
+        t.intercept = cfg.intercept; t.onepl = cfg.one_pl; t.cov2one = cfg.cov2one; t.sigp_mode = cfg.sigp_mode;
+        t.chain = (uint32_t)cfg.chain_id; t.seed = cfg.seed;
+        const double q = cfg.q_rt;
+        t.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); t.k2 = 2.0 / (q * (1.0 - q));
+        t.nq = nq();
+        return t;
+    }
+
+    int64_t n_pass_timed = 0;
+    template <int MODEL, int PHASE> int launch_pass(int mode, bool timed) {
+        PassArgs<real> a = pass_args(PHASE, mode);
+        const bool ev = timed && cfg.profile && (size_t)(2 * n_pass_timed + 1) < pass_ev.size();
+        if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed], stream));
+        hipLaunchKernelGGL((pass_kernel<MODEL, real, PHASE>), dim3(grid_blocks), dim3(block_threads), lds_pass[PHASE], stream, a);
+        if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed + 1], stream)); ++n_pass_timed; }
+        return 0;
+    }
+    template <int MODEL, int STEP> int launch_tiny(int mode, int first) {
+        TinyArgs t = tiny_args(mode, first);
+        hipLaunchKernelGGL((tiny_kernel<MODEL, STEP>), dim3(1), dim3(TINY_THREADS), tiny_lds(), stream, t);
+        return 0;
+    }
+
+    template <int MODEL> int run_model(int64_t nsweeps) {
+        // prologue: omega_{t+1} (and nu_{t+1}) and the statistics of the current state
+        if (int rc = launch_pass<MODEL, 0>(0, false)) return rc;
+        if constexpr (MODEL == CROSSQR) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
+        for (int64_t k = 0; k < nsweeps; ++k) {
+            if (int rc = launch_tiny<MODEL, 0>(0, k == 0)) return rc;
+            if (int rc = launch_pass<MODEL, 0>(1, true)) return rc;
+            if constexpr (MODEL == CROSSQR) {
+                if (int rc = launch_tiny<MODEL, 1>(0, 0)) return rc;
+                if (int rc = launch_pass<MODEL, 1>(1, true)) return rc;
+            }
+        }
+        if (int rc = launch_tiny<MODEL, 0>(1, nsweeps == 0)) return rc;
+        return 0;
+    }
+
+    int run(int64_t nsweeps) override {
+        if (!has_data) return fail(ERM_ERR_STATE, "erm_set_data has not been called");
+        if (nsweeps < 0) return fail(ERM_ERR_ARG, "nsweeps must be non-negative");
+        if (rows_done + nsweeps > rows_cap) return fail(ERM_ERR_ARG, "trace capacity exceeded: n_iter*n_chain rows were allocated");
+        HIPCHK(hipSetDevice(cfg.device));
+        Ctl c{};
+        c.sweep = sweeps_total; c.row = (uint32_t)rows_done; c.burn_rows = (uint32_t)((int64_t)cfg.n_burnin * cfg.n_chain); c.err = 0;
+        HIPCHK(hipMemcpyAsync(dCtl.p, &c, sizeof(Ctl), hipMemcpyHostToDevice, stream));
+        n_pass_timed = 0;
+        HIPCHK(hipEventRecord(ev0, stream));
+        int rc = 0;
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: rc = run_model<MLIRT>(nsweeps); break;
+        case ERM_MODEL_RTIRT: rc = run_model<RTIRT>(nsweeps); break;
+        case ERM_MODEL_LATENTQR: rc = run_model<LATENTQR>(nsweeps); break;
+        default: rc = run_model<CROSSQR>(nsweeps);
+        }
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(ev1, stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+        timing.run_ms = ms; timing.sweeps = nsweeps; timing.pass_ms_total = 0.0; timing.pass_launches = n_pass_timed;
+        for (int64_t k = 0; k < n_pass_timed; ++k) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, pass_ev[2 * k], pass_ev[2 * k + 1]));
+            timing.pass_ms_total += t;
+        }
+        Ctl back{};
+        HIPCHK(hipMemcpy(&back, dCtl.p, sizeof(Ctl), hipMemcpyDeviceToHost));
+        const int64_t burn = (int64_t)cfg.n_burnin * cfg.n_chain;
+        const int64_t lo = std::max<int64_t>(rows_done, burn), hi = rows_done + nsweeps;
+        if (hi > lo) post_rows += hi - lo;
+        rows_done += nsweeps;
+        sweeps_total += (uint32_t)nsweeps;
+        if (back.err) return fail(ERM_ERR_NONFINITE, "non-finite item parameter encountered");
+        return 0;
+    }
+
+    int reset_trace() override {
+        rows_done = 0; post_rows = 0;
+        HIPCHK(hipMemset(dSumTheta.p, 0, dSumTheta.bytes));
+        HIPCHK(hipMemset(dSumZeta.p, 0, dSumZeta.bytes));
+        if (dSumNu.p) HIPCHK(hipMemset(dSumNu.p, 0, dSumNu.bytes));
+        return 0;
+    }
+
+    // -------------------------------------------------------------------------------------------- data
+    int set_data(const uint8_t* Y, const double* logT, const double* X) override {
+        if (!Y) return fail(ERM_ERR_ARG, "Y is NULL");
+        if (is_rt() && !logT) return fail(ERM_ERR_ARG, "logT is required for response-time models");
+        if (Fk > 0 && !X) return fail(ERM_ERR_ARG, "X is required when n_feat > 0");
+        HIPCHK(hipSetDevice(cfg.device));
+        const size_t NJ = (size_t)N * J;
+        std::vector<double> cst(cst_size(J), 0.0);
+        {   // Y -> row-major bytes; K0_j = sum_i kappa_ij  (kappa = Y - 0.5, src/Base.pl.jl:74)
+            std::vector<uint8_t> yr(NJ);
+            for (int j = 0; j < J; ++j) {
+                double k0 = 0.0;
+                const uint8_t* col = Y + (size_t)j * N;
+                for (int64_t i = 0; i < N; ++i) {
+                    if (col[i] > 1) return fail(ERM_ERR_ARG, "Y must be 0/1");
+                    yr[(size_t)i * J + j] = col[i];
+                    k0 += (double)col[i] - 0.5;
+                }
+                cst[cst_off_k0(J) + j] = k0;
+            }
+            HIPCHK(hipMemcpy(dY.p, yr.data(), NJ, hipMemcpyHostToDevice));
+        }
+        if (is_rt()) {
+            // column-centred logT; mean/std(Data.logT) are the kwargs of drawItemIntensity (src/Draw.pl.jl:215)
+            std::vector<real> cr(NJ);
+            double tot = 0.0;
+            for (int j = 0; j < J; ++j) {
+                const double* col = logT + (size_t)j * N;
+                double sm = 0.0;
+                for (int64_t i = 0; i < N; ++i) { if (!std::isfinite(col[i])) return fail(ERM_ERR_ARG, "logT must be finite"); sm += col[i]; }
+                tot += sm;
+                const double m = sm / (double)N;
+                double sq = 0.0;
+                for (int64_t i = 0; i < N; ++i) { const double c = col[i] - m; sq += c * c; cr[(size_t)i * J + j] = (real)c; }
+                cst[cst_off_m(J) + j] = m; cst[cst_off_csq(J) + j] = sq;
+            }
+            const double mu = tot / (double)NJ;
+            double ss = 0.0;
+            for (int j = 0; j < J; ++j) { const double dm = cst[cst_off_m(J) + j] - mu; ss += cst[cst_off_csq(J) + j] + (double)N * dm * dm; }
+            cst[cst_off_mu(J)] = mu; cst[cst_off_mu(J) + 1] = std::sqrt(ss / (double)(NJ - 1));
+            HIPCHK(hipMemcpy(dC.p, cr.data(), NJ * sizeof(real), hipMemcpyHostToDevice));
+        }
+        {   // X -> row-major; x'x with x = [1 X]
+            const int pp = p();
+            std::vector<real> xr((size_t)N * std::max(Fk, 1));
+            for (int u = 0; u < pp; ++u) for (int v = 0; v < pp; ++v) {
+                double t = 0.0;
+                for (int64_t i = 0; i < N; ++i) {
+                    const double xu = u == 0 ? 1.0 : X[(size_t)(u - 1) * N + i], xv = v == 0 ? 1.0 : X[(size_t)(v - 1) * N + i];
+                    t += xu * xv;
+                }
+                cst[cst_off_xtx(J) + u + v * PMAX] = t;
+            }
+            if (Fk > 0) {
+                for (int f = 0; f < Fk; ++f) for (int64_t i = 0; i < N; ++i) xr[(size_t)i * Fk + f] = (real)X[(size_t)f * N + i];
+                HIPCHK(hipMemcpy(dX.p, xr.data(), (size_t)N * Fk * sizeof(real), hipMemcpyHostToDevice));
+            }
+        }
+        HIPCHK(hipMemcpy(dCst.p, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
+        has_data = true;
+        return 0;
+    }
+
+    int nbeta() const {
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: return F + 1;
+        case ERM_MODEL_RTIRT: return 2 * (F + 1);
+        case ERM_MODEL_LATENTQR: return F + 2;
+        default: return 0;
+        }
+    }
+
+    int up_real(DevBuf& d, const double* src, size_t n) {
+        std::vector<real> t(n);
+        for (size_t k = 0; k < n; ++k) t[k] = (real)src[k];
+        HIPCHK(hipMemcpy(d.p, t.data(), n * sizeof(real), hipMemcpyHostToDevice));
+        return 0;
+    }
+    int down_real(const DevBuf& d, double* dst, size_t n) {
+        std::vector<real> t(n);
+        HIPCHK(hipMemcpy(t.data(), d.p, n * sizeof(real), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < n; ++k) dst[k] = (double)t[k];
+        return 0;
+    }
+
+    int set_state(const erm_state* st) override {
+        if (!st) return fail(ERM_ERR_ARG, "state is NULL");
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<double> par(par_size(J));
+        HIPCHK(hipMemcpy(par.data(), dPar.p, par.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (st->a) memcpy(&par[0], st->a, J * sizeof(double));
+        if (st->b) memcpy(&par[J], st->b, J * sizeof(double));
+        if (st->lambda) memcpy(&par[2 * J], st->lambda, J * sizeof(double));
+        if (st->sig2t) { for (int j = 0; j < J; ++j) if (!(st->sig2t[j] > 0.0)) return fail(ERM_ERR_ARG, "sig2t must be positive"); memcpy(&par[3 * J], st->sig2t, J * sizeof(double)); }
+        if (st->rho) memcpy(&par[4 * J], st->rho, J * sizeof(double));
+        if (st->sigp) memcpy(&par[par_off_sigp(J)], st->sigp, 4 * sizeof(double));
+        if (st->beta) {
+            double* b = &par[par_off_beta(J)];
+            const int pp = F + 1;
+            if (cfg.model == ERM_MODEL_RTIRT) { for (int u = 0; u < pp; ++u) { b[u] = st->beta[u]; b[PMAX + u] = st->beta[pp + u]; } }
+            else for (int u = 0; u < nbeta(); ++u) b[u] = st->beta[u];
+        }
+        HIPCHK(hipMemcpy(dPar.p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (st->theta) if (int rc = up_real(dTheta, st->theta, N)) return rc;
+        if (st->zeta) if (int rc = up_real(dZeta, st->zeta, N)) return rc;
+        if (st->nu && dNu.p) {
+            if (cfg.model == ERM_MODEL_LATENTQR) { if (int rc = up_real(dNu, st->nu, N)) return rc; }
+            else {
+                std::vector<real> t((size_t)N * J);
+                for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) {
+                    const double v = st->nu[(size_t)j * N + i];
+                    if (!(v > 0.0)) return fail(ERM_ERR_ARG, "nu must be positive");   // @assert src/Draw.pl.jl:477
+                    t[(size_t)i * J + j] = (real)v;
+                }
+                HIPCHK(hipMemcpy(dNu.p, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
+            }
+        }
+        return 0;
+    }
+
+    int get_state(erm_state* st) override {
+        if (!st) return fail(ERM_ERR_ARG, "state is NULL");
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<double> par(par_size(J));
+        HIPCHK(hipMemcpy(par.data(), dPar.p, par.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (st->a) memcpy(st->a, &par[0], J * sizeof(double));
+        if (st->b) memcpy(st->b, &par[J], J * sizeof(double));
+        if (st->lambda) memcpy(st->lambda, &par[2 * J], J * sizeof(double));
+        if (st->sig2t) memcpy(st->sig2t, &par[3 * J], J * sizeof(double));
+        if (st->rho) memcpy(st->rho, &par[4 * J], J * sizeof(double));
+        if (st->sigp) memcpy(st->sigp, &par[par_off_sigp(J)], 4 * sizeof(double));
+        if (st->beta) {
+            const double* b = &par[par_off_beta(J)];
+            const int pp = F + 1;
+            if (cfg.model == ERM_MODEL_RTIRT) { for (int u = 0; u < pp; ++u) { st->beta[u] = b[u]; st->beta[pp + u] = b[PMAX + u]; } }
+            else for (int u = 0; u < nbeta(); ++u) st->beta[u] = b[u];
+        }
+        if (st->theta) if (int rc = down_real(dTheta, st->theta, N)) return rc;
+        if (st->zeta) if (int rc = down_real(dZeta, st->zeta, N)) return rc;
+        if (st->nu && dNu.p) {
+            if (cfg.model == ERM_MODEL_LATENTQR) { if (int rc = down_real(dNu, st->nu, N)) return rc; }
+            else {
+                std::vector<real> t((size_t)N * J);
+                HIPCHK(hipMemcpy(t.data(), dNu.p, t.size() * sizeof(real), hipMemcpyDeviceToHost));
+                for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) st->nu[(size_t)j * N + i] = (double)t[(size_t)i * J + j];
+            }
+        }
+        return 0;
+    }
+
+    // -------------------------------------------------------------------------------------------- traces
+    int fetch_item_trace(std::vector<double>& it) {
+        it.resize((size_t)std::max<int64_t>(rows_done, 0) * item_trace_width());
+        if (!it.empty()) HIPCHK(hipMemcpy(it.data(), dTrItem.p, it.size() * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    int get_item_trace(double* out) override {
+        HIPCHK(hipSetDevice(cfg.device));
+        std::vector<double> it;
+        if (int rc = fetch_item_trace(it)) return rc;
+        if (!it.empty()) memcpy(out, it.data(), it.size() * sizeof(double));
+        return 0;
+    }
+
+    // Julia layout [nIter][width][nChain], nIter fastest; trace row r = m*nChain + l
+    int get_trace(int which, double* out) override {
+        HIPCHK(hipSetDevice(cfg.device));
+        const int64_t nIter = cfg.n_iter, nChain = cfg.n_chain, wd = trace_width(which);
+        if (wd <= 0) return fail(ERM_ERR_ARG, "this model has no such trace");
+        if (rows_done != rows_cap) return fail(ERM_ERR_STATE, "trace incomplete: run n_iter*n_chain sweeps first");
+        auto at = [&](int64_t r, int64_t k) -> double& { const int64_t m = r / nChain, l = r % nChain; return out[m + nIter * (k + wd * l)]; };
+        if (which == ERM_TRACE_LOGLIKE) {
+            std::vector<double> ll(rows_cap);
+            HIPCHK(hipMemcpy(ll.data(), dTrLl.p, rows_cap * sizeof(double), hipMemcpyDeviceToHost));
+            for (int64_t r = 0; r < rows_cap; ++r) at(r, 0) = ll[r];
+            return 0;
+        }
+        if (cfg.trace_mode != ERM_TRACE_FULL) return fail(ERM_ERR_NOTRACE, "subject-level traces need trace_mode = ERM_TRACE_FULL");
+        if (which == ERM_TRACE_QR && cfg.model == ERM_MODEL_CROSSQR)
+            return fail(ERM_ERR_NOTRACE, "CrossQr keeps only the running mean of nu (N*J values per sweep are not stored); use erm_get_item_trace + erm_get_mean");
+        std::vector<double> it;
+        if (int rc = fetch_item_trace(it)) return rc;
+        const int64_t wi = item_trace_width();
+        std::vector<real> rowbuf(N);
+        auto subj = [&](const DevBuf& d, int64_t k0) -> int {
+            for (int64_t r = 0; r < rows_cap; ++r) {
+                HIPCHK(hipMemcpy(rowbuf.data(), d.as<real>() + (size_t)r * N, N * sizeof(real), hipMemcpyDeviceToHost));
+                for (int64_t i = 0; i < N; ++i) at(r, k0 + i) = (double)rowbuf[i];
+            }
+            return 0;
+        };
+        if (which == ERM_TRACE_RA) {            // [theta; a; b]  src/GibbsRtIrt.pl.jl:242,320
+            if (int rc = subj(dTrTheta, 0)) return rc;
+            for (int64_t r = 0; r < rows_cap; ++r) for (int j = 0; j < J; ++j) { at(r, N + j) = it[r * wi + j]; at(r, N + J + j) = it[r * wi + J + j]; }
+        } else if (which == ERM_TRACE_RT) {     // [zeta; lambda; sig2t]  :321
+            if (int rc = subj(dTrZeta, 0)) return rc;
+            for (int64_t r = 0; r < rows_cap; ++r) for (int j = 0; j < J; ++j) { at(r, N + j) = it[r * wi + 2 * J + j]; at(r, N + J + j) = it[r * wi + 3 * J + j]; }
+        } else {                                 // qr  :241,319 ; Latent :308
+            const int q = nq();
+            for (int64_t r = 0; r < rows_cap; ++r) for (int k = 0; k < q; ++k) at(r, k) = it[r * wi + 4 * J + k];
+            if (cfg.model == ERM_MODEL_LATENTQR) if (int rc = subj(dTrNu, q)) return rc;
+        }
+        return 0;
+    }
+
+    int get_mean(erm_state* out) override {
+        if (!out) return fail(ERM_ERR_ARG, "state is NULL");
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (post_rows <= 0) return fail(ERM_ERR_STATE, "no post-burn-in sweeps recorded");
+        const double inv = 1.0 / (double)post_rows;
+        auto subj = [&](const DevBuf& d, double* dst, size_t n, bool transpose) -> int {
+            std::vector<double> t(n);
+            HIPCHK(hipMemcpy(t.data(), d.p, n * sizeof(double), hipMemcpyDeviceToHost));
+            if (!transpose) for (size_t k = 0; k < n; ++k) dst[k] = t[k] * inv;
+            else for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) dst[(size_t)j * N + i] = t[(size_t)i * J + j] * inv;
+            return 0;
+        };
+        if (out->theta) if (int rc = subj(dSumTheta, out->theta, N, false)) return rc;
+        if (out->zeta && is_rt()) if (int rc = subj(dSumZeta, out->zeta, N, false)) return rc;
+        if (out->nu && dSumNu.p) {
+            if (cfg.model == ERM_MODEL_LATENTQR) { if (int rc = subj(dSumNu, out->nu, N, false)) return rc; }
+            else if (int rc = subj(dSumNu, out->nu, (size_t)N * J, true)) return rc;
+        }
+        std::vector<double> it;
+        if (int rc = fetch_item_trace(it)) return rc;
+        const int64_t wi = item_trace_width(), burn = (int64_t)cfg.n_burnin * cfg.n_chain;
+        std::vector<double> m(wi, 0.0);
+        for (int64_t r = burn; r < rows_done; ++r) for (int64_t k = 0; k < wi; ++k) m[k] += it[r * wi + k];
+        for (auto& v : m) v *= inv;
+        if (out->a) memcpy(out->a, &m[0], J * sizeof(double));
+        if (out->b) memcpy(out->b, &m[J], J * sizeof(double));
+        if (out->lambda) memcpy(out->lambda, &m[2 * J], J * sizeof(double));
+        if (out->sig2t) memcpy(out->sig2t, &m[3 * J], J * sizeof(double));
+        const double* q = &m[4 * J];
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: if (out->beta) memcpy(out->beta, q, (F + 1) * sizeof(double)); break;
+        case ERM_MODEL_RTIRT: if (out->beta) memcpy(out->beta, q, 2 * (F + 1) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + 2 * (F + 1), 4 * sizeof(double)); break;
+        case ERM_MODEL_CROSSQR: if (out->rho) memcpy(out->rho, q, J * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + J, 4 * sizeof(double)); break;
+        default: if (out->beta) memcpy(out->beta, q, (F + 2) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + F + 2, 4 * sizeof(double));
+        }
+        return 0;
+    }
+};
+
+}  // namespace
+
+struct erm_engine { std::unique_ptr<EngineBase> e; };
+
+extern "C" {
+
+int erm_create(const erm_config* cfg, erm_handle* out)
+{
+    if (!cfg || !out) return fail(ERM_ERR_ARG, "cfg/out is NULL");
+    *out = nullptr;
+    std::unique_ptr<EngineBase> e;
+    if (cfg->precision == ERM_PREC_F32) e.reset(new Engine<float>());
+    else if (cfg->precision == ERM_PREC_F64) e.reset(new Engine<double>());
+    else return fail(ERM_ERR_ARG, "unknown precision");
+    e->cfg = *cfg;
+    if (int rc = e->init()) return rc;
+    *out = new erm_engine{std::move(e)};
+    return ERM_OK;
+}
+void erm_destroy(erm_handle h) { delete h; }
+#define CHK_H if (!h) return fail(ERM_ERR_ARG, "handle is NULL")
+int erm_set_data(erm_handle h, const uint8_t* Y, const double* logT, const double* X) { CHK_H; return h->e->set_data(Y, logT, X); }
+int erm_set_state(erm_handle h, const erm_state* st) { CHK_H; return h->e->set_state(st); }
+int erm_get_state(erm_handle h, erm_state* st) { CHK_H; return h->e->get_state(st); }
+int erm_run(erm_handle h, int64_t nsweeps) { CHK_H; return h->e->run(nsweeps); }
+int64_t erm_rows_done(erm_handle h) { return h ? h->e->rows_done : -1; }
+int erm_reset_trace(erm_handle h) { CHK_H; return h->e->reset_trace(); }
+int64_t erm_trace_width(erm_handle h, int which) { return h ? h->e->trace_width(which) : -1; }
+int erm_get_trace(erm_handle h, int which, double* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_trace(which, out); }
+int64_t erm_item_trace_width(erm_handle h) { return h ? h->e->item_trace_width() : -1; }
+int erm_get_item_trace(erm_handle h, double* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_item_trace(out); }
+int erm_get_mean(erm_handle h, erm_state* out) { CHK_H; return h->e->get_mean(out); }
+int64_t erm_post_count(erm_handle h) { return h ? h->e->post_rows : -1; }
+int erm_get_timing(erm_handle h, erm_timing* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); *out = h->e->timing; return 0; }
+const char* erm_last_error(void) { return g_err.c_str(); }
+const char* erm_version(void) { return "ertirt-amd 0.1.0 (gfx950)"; }
+
+int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32_t site, uint32_t sweep, int64_t n,
+                     const double* par0, const double* par1, double* out)
+{
+    if (n <= 0 || !out) return fail(ERM_ERR_ARG, "bad n/out");
+    HIPCHK(hipSetDevice(device));
+    DevBuf d0, d1, dout;
+    if (int rc = dout.alloc(n * sizeof(double))) return rc;
+    if (par0) { if (int rc = d0.alloc(n * sizeof(double))) return rc; HIPCHK(hipMemcpy(d0.p, par0, n * sizeof(double), hipMemcpyHostToDevice)); }
+    if (par1) { if (int rc = d1.alloc(n * sizeof(double))) return rc; HIPCHK(hipMemcpy(d1.p, par1, n * sizeof(double), hipMemcpyHostToDevice)); }
+    const int bt = 256; const int gb = (int)((n + bt - 1) / bt);
+    if (precision == ERM_PREC_F32)
+        hipLaunchKernelGGL((sample_batch_kernel<float>), dim3(gb), dim3(bt), 0, 0, which, seed, site, sweep, (long long)n, d0.as<double>(), d1.as<double>(), dout.as<double>());
+    else
+        hipLaunchKernelGGL((sample_batch_kernel<double>), dim3(gb), dim3(bt), 0, 0, which, seed, site, sweep, (long long)n, d0.as<double>(), d1.as<double>(), dout.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+"""Sampler objects and `sample!` for the MI355X engine -- host-side mirror of
+/root/reference/src/GibbsRtIrt.pl.jl:35-472, src/GibbsRtIrtCross.pl.jl:55-353, src/GibbsRtIrtLatent.pl.jl:50-365.
+
+Same struct names, fields (Cond, Data, truePara, Para, Post), constructor behaviour (always (re)initialises Para and
+allocates Post), kwargs and error text as the reference.  `sample!` is spelled `sample_b` (PyJulia's convention for `!`)
+and is also exported as `sample`.  All sampling happens in libertirt.so on the GPU; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .base import InputPara, OutputDic, SimConditions
+
+_PREC = {"f32": _lib.PREC_F32, "f64": _lib.PREC_F64}
+_TRACE = {"summary": _lib.TRACE_SUMMARY, "full": _lib.TRACE_FULL}
+
+
+class _OutputPost:
+    """OutputPostMlIrt / OutputPost / OutputPostCrossQr / OutputPostRtIrtLatentQr
+    (src/GibbsRtIrt.pl.jl:35-71, src/GibbsRtIrtCross.pl.jl:55-69, src/GibbsRtIrtLatent.pl.jl:50-64).
+    ra, rt, qr: (nIter, width, nChain); logLike: (nIter, 1, nChain); mean: InputPara with flat vectors."""
+
+    def __init__(self):
+        self.ra = np.zeros(0)
+        self.rt = np.zeros(0)
+        self.qr = np.zeros(0)
+        self.logLike = np.zeros(0)
+        self.mean = InputPara()
+
+
+class _GibbsBase:
+    _model = None
+    _cov2one_default = True
+    _has_intercept = True
+
+    def __init__(self, Cond: SimConditions, *, Data=None, truePara=None, Para=None, Post=None,
+                 seed=1234, device=0, precision="f32", trace="full", chain_id=0, **engine_opts):
+        self.Cond = Cond
+        self.Data = Data
+        self.truePara = truePara
+        self.seed = int(seed)
+        self.device = int(device)
+        self.precision = precision
+        self.trace = trace
+        self.chain_id = int(chain_id)
+        self.engine_opts = dict(engine_opts)
+        self._engine = None
+        self._engine_key = None
+        self.Para = None
+        self.setInitialValues()          # constructors always overwrite Para (src/GibbsRtIrt.pl.jl:100-102)
+        self.Post = _OutputPost()
+
+    # -- per-model hooks
+    def setInitialValues(self):
+        raise NotImplementedError
+
+    def _rng(self):
+        return np.random.default_rng(np.random.SeedSequence([self.seed, self.chain_id, 0x1217]))
+
+    def _state_for_engine(self):
+        P = self.Para
+        d = dict(theta=P.theta, a=P.a, b=P.b)
+        if self._model != _lib.MODEL_MLIRT:
+            d.update(zeta=P.zeta, lambda_=P.lam, sig2t=P.sig2t, sigp=np.asarray(P.Sigp, dtype=np.float64).reshape(-1, order="F"))
+        if P.beta.size:
+            d["beta"] = np.asarray(P.beta, dtype=np.float64).reshape(-1, order="F")
+        if P.rho.size:
+            d["rho"] = P.rho
+        if P.nu.size and self._model in (_lib.MODEL_CROSSQR, _lib.MODEL_LATENTQR):
+            d["nu"] = np.asarray(P.nu, dtype=np.float64).reshape(-1, order="F")
+        return d
+
+    def _engine_for(self, intercept, onepl, cov2one):
+        key = (bool(intercept), bool(onepl), bool(cov2one))
+        if self._engine is not None and self._engine_key == key:
+            return self._engine
+        if self._engine is not None:
+            self._engine.close()
+        C = self.Cond
+        if self.Data is None:
+            raise ValueError("Data is required")
+        eng = _lib.Engine(model=self._model, n_item=C.nItem, n_subj=C.nSubj, n_feat=C.nFeat, n_iter=C.nIter, n_chain=C.nChain,
+                          n_burnin=C.nBurnin, intercept=int(intercept), one_pl=int(onepl), cov2one=int(cov2one), q_rt=C.qRt,
+                          seed=self.seed, chain_id=self.chain_id, device=self.device, precision=_PREC[self.precision],
+                          trace_mode=_TRACE[self.trace], **self.engine_opts)
+        D = self.Data
+        Y = np.asarray(D.Y)
+        if Y.shape != (C.nSubj, C.nItem):
+            raise ValueError(f"Data.Y must be {C.nSubj}x{C.nItem}, got {Y.shape}")
+        logT = None
+        if self._model != _lib.MODEL_MLIRT:
+            logT = np.asarray(D.logT, dtype=np.float64)
+            if logT.shape != (C.nSubj, C.nItem):
+                raise ValueError(f"Data.logT must be {C.nSubj}x{C.nItem}, got {logT.shape}")
+        X = None
+        if self._model != _lib.MODEL_CROSSQR and C.nFeat > 0:
+            X = np.asarray(D.X, dtype=np.float64)
+            if X.shape != (C.nSubj, C.nFeat):
+                raise ValueError(f"Data.X must be {C.nSubj}x{C.nFeat}, got {X.shape}")
+        eng.set_data(Y, logT, X)
+        self._engine, self._engine_key = eng, key
+        return eng
+
+    def _fill_post(self, eng):
+        C = self.Cond
+        Post = self.Post
+        full = self.trace == "full"
+        Post.logLike = eng.trace(_lib.TRACE_LOGLIKE)
+        if full:
+            Post.ra = eng.trace(_lib.TRACE_RA)
+            if self._model != _lib.MODEL_MLIRT:
+                Post.rt = eng.trace(_lib.TRACE_RT)
+            if self._model != _lib.MODEL_CROSSQR:
+                Post.qr = eng.trace(_lib.TRACE_QR)
+        Post.item_trace = eng.item_trace()
+        m = eng.get_mean()
+        mean = InputPara(theta=m["theta"], a=m["a"], b=m["b"])
+        if self._model != _lib.MODEL_MLIRT:
+            mean.zeta, mean.lam, mean.sig2t = m["zeta"], m["lambda_"], m["sig2t"]
+            mean.Sigp = m["sigp"]
+        if m["beta"] is not None:
+            mean.beta = m["beta"]
+        if self._model == _lib.MODEL_CROSSQR:
+            mean.rho = m["rho"]
+        if m["nu"] is not None:
+            mean.nu = m["nu"]
+        Post.mean = mean
+
+    def _update_para(self, eng):
+        s = eng.get_state()
+        C = self.Cond
+        P = self.Para
+        P.theta, P.a, P.b = s["theta"], s["a"], s["b"]
+        if self._model != _lib.MODEL_MLIRT:
+            P.zeta, P.lam, P.sig2t = s["zeta"], s["lambda_"], s["sig2t"]
+            P.Sigp = s["sigp"].reshape(2, 2, order="F")
+        if s["beta"] is not None:
+            P.beta = s["beta"].reshape(C.nFeat + 1, 2, order="F") if self._model == _lib.MODEL_RTIRT else s["beta"]
+        if self._model == _lib.MODEL_CROSSQR:
+            P.rho = s["rho"]
+            P.nu = s["nu"].reshape(C.nSubj, C.nItem, order="F")
+        if self._model == _lib.MODEL_LATENTQR:
+            P.nu = s["nu"]
+
+    def timing(self):
+        return self._engine.timing() if self._engine is not None else None
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+
+def sample_b(MCMC: _GibbsBase, *, intercept=False, itemtype="2pl", cov2one=None):
+    """sample!(MCMC; intercept, itemtype, cov2one) -- src/GibbsRtIrt.pl.jl:210,278; Cross :265; Latent :271.
+    Runs Cond.nIter * Cond.nChain sweeps (the reference's interleaved `for m in 1:nIter, l in 1:nChain` loop over ONE
+    shared Para), fills MCMC.Post, leaves the final state in MCMC.Para and returns MCMC."""
+    if itemtype not in ("1pl", "2pl"):
+        raise ValueError("Invalid input: the item type must be '1pl' or '2pl'.")   # same text as :213,281
+    if cov2one is None:
+        cov2one = MCMC._cov2one_default
+    if intercept and not MCMC._has_intercept:
+        raise TypeError(f"sample! for {type(MCMC).__name__} has no `intercept` keyword")
+    eng = MCMC._engine_for(intercept, itemtype == "1pl", cov2one)
+    eng.reset_trace()
+    eng.set_state(**MCMC._state_for_engine())
+    eng.run(MCMC.Cond.nIter * MCMC.Cond.nChain)
+    MCMC._fill_post(eng)
+    MCMC._update_para(eng)
+    return MCMC
+
+
+sample = sample_b
+
+
+class GibbsMlIrt(_GibbsBase):
+    """src/GibbsRtIrt.pl.jl:76-106.  theta's prior variance is 1 (the reference never sets Para.Σp for this model:
+    :85-91, :228; its likelihood uses Normal(mu, 1.) :201)."""
+    _model = _lib.MODEL_MLIRT
+
+    def setInitialValues(self):
+        C, g = self.Cond, self._rng()
+        self.Para = InputPara(theta=g.standard_normal(C.nSubj), a=np.ones(C.nItem), b=np.zeros(C.nItem),
+                              beta=g.standard_normal(C.nFeat + 1))
+        return self
+
+
+class GibbsRtIrt(_GibbsBase):
+    """src/GibbsRtIrt.pl.jl:114-146"""
+    _model = _lib.MODEL_RTIRT
+
+    def setInitialValues(self):
+        C, g = self.Cond, self._rng()
+        self.Para = InputPara(theta=g.standard_normal(C.nSubj), a=np.ones(C.nItem), b=np.zeros(C.nItem),
+                              zeta=g.standard_normal(C.nSubj), lam=np.zeros(C.nItem), sig2t=np.ones(C.nItem),
+                              beta=g.standard_normal((C.nFeat + 1, 2)), Sigp=np.eye(2))
+        return self
+
+
+class GibbsRtIrtCrossQr(_GibbsBase):
+    """src/GibbsRtIrtCross.pl.jl:115-147"""
+    _model = _lib.MODEL_CROSSQR
+    _has_intercept = False
+
+    def setInitialValues(self):
+        C, g = self.Cond, self._rng()
+        self.Para = InputPara(theta=g.standard_normal(C.nSubj), a=np.ones(C.nItem), b=np.zeros(C.nItem),
+                              zeta=g.standard_normal(C.nSubj), lam=np.zeros(C.nItem), sig2t=np.ones(C.nItem),
+                              rho=g.standard_normal(C.nItem), Sigp=np.eye(2))
+        return self
+
+
+class GibbsRtIrtLatentQr(_GibbsBase):
+    """src/GibbsRtIrtLatent.pl.jl:105-137 (sample! default cov2one = false, :271)"""
+    _model = _lib.MODEL_LATENTQR
+    _cov2one_default = False
+
+    def setInitialValues(self):
+        C, g = self.Cond, self._rng()
+        self.Para = InputPara(theta=g.standard_normal(C.nSubj), a=np.ones(C.nItem), b=np.zeros(C.nItem),
+                              zeta=g.standard_normal(C.nSubj), lam=np.zeros(C.nItem), sig2t=np.ones(C.nItem),
+                              beta=g.standard_normal(C.nFeat + 2), Sigp=np.eye(2))
+        return self
+
+
+# README.md:22,95 names `GibbsRtIrtQuantile`; the export is commented out in the reference (src/ExtendedRtIrtModeling.jl:65) and
+# the only live type with that API (X, beta, Sigp, qRt) is GibbsRtIrtLatentQr.
+GibbsRtIrtQuantile = GibbsRtIrtLatentQr
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# log-likelihoods at a parameter point and DIC (host-side post-processing, numpy fp64)
+# ------------------------------------------------------------------------------------------------------------------
+def _log1pexp(x):
+    return np.where(x > 0, x + np.log1p(np.exp(-np.abs(x))), np.log1p(np.exp(-np.abs(x))))
+
+
+def _norm_logpdf(x, mu, sd):
+    return -0.5 * np.log(2 * np.pi) - np.log(sd) - 0.5 * ((x - mu) / sd) ** 2
+
+
+def getLogLikelihood(MCMC: _GibbsBase, P: InputPara) -> float:
+    """getLogLikelihoodMlIrt / RtIrt / RtIrtCrossQr / RtIrtLatentQr evaluated at P
+    (src/GibbsRtIrt.pl.jl:195-204,262-272; src/GibbsRtIrtCross.pl.jl:240-258; src/GibbsRtIrtLatent.pl.jl:243-264)."""
+    C, D = MCMC.Cond, MCMC.Data
+    Y = np.asarray(D.Y, dtype=np.float64)
+    th, a, b = P.theta, P.a, P.b
+    pr = a[None, :] * (th[:, None] - b[None, :])
+    ll = np.sum(Y * pr - _log1pexp(pr))
+    m = MCMC._model
+    if m == _lib.MODEL_MLIRT:
+        x = np.column_stack([np.ones(C.nSubj), D.X])
+        return float(ll + np.sum(_norm_logpdf(th, x @ P.beta, 1.0)))
+    q = C.qRt
+    k1, k2 = (1 - 2 * q) / (q * (1 - q)), 2 / (q * (1 - q))
+    logT = np.asarray(D.logT, dtype=np.float64)
+    if m == _lib.MODEL_CROSSQR:
+        e = np.asarray(P.nu).reshape(C.nSubj, C.nItem, order="F")
+        mut = P.lam[None, :] - P.zeta[:, None] - th[:, None] * P.rho[None, :] + k1 * e
+        ll += np.sum(_norm_logpdf(logT, mut, np.sqrt(P.sig2t[None, :] * (k2 * e))))
+    else:
+        ll += np.sum(_norm_logpdf(logT, P.lam[None, :] - P.zeta[:, None], np.sqrt(P.sig2t)[None, :]))
+    S = np.asarray(P.Sigp, dtype=np.float64).reshape(2, 2, order="F")
+    if m in (_lib.MODEL_RTIRT, _lib.MODEL_CROSSQR):
+        eta = np.column_stack([th, P.zeta])
+        if m == _lib.MODEL_RTIRT:
+            x = np.column_stack([np.ones(C.nSubj), D.X])
+            eta = eta - x @ np.asarray(P.beta).reshape(C.nFeat + 1, 2, order="F")
+        Si = np.linalg.inv(S)
+        quad = np.einsum("ia,ab,ib->i", eta, Si, eta)
+        ll += np.sum(-np.log(2 * np.pi) - 0.5 * np.log(np.linalg.det(S)) - 0.5 * quad)
+    else:
+        x = np.column_stack([np.ones(C.nSubj), D.X, th])
+        ll += np.sum(_norm_logpdf(P.zeta, x @ P.beta + k1 * P.nu, np.sqrt(S[1, 1] * k2 * P.nu)))
+    return float(ll)
+
+
+def getDic(MCMC: _GibbsBase) -> OutputDic:
+    """src/GibbsRtIrt.pl.jl:432-458 (and Cross :329-353, Latent :341-365): D̂ = -2 logLik(Post.mean),
+    D̄ = -2 mean(Post.logLike) over ALL iterations (burn-in included, as the reference does)."""
+    Dhat = -2.0 * getLogLikelihood(MCMC, MCMC.Post.mean)
+    Dbar = -2.0 * float(np.mean(MCMC.Post.logLike))
+    pD = Dbar - Dhat
+    return OutputDic(pD=pD, DIC=Dbar + pD)
+
+
+def coef(MCMC: _GibbsBase) -> dict:
+    """Posterior-mean tables of `coef` (src/GibbsRtIrt.pl.jl:479-538) as plain arrays (pretty-printing is out of scope)."""
+    C, M = MCMC.Cond, MCMC.Post.mean
+    out = {"a": M.a, "b": M.b}
+    if MCMC._model != _lib.MODEL_MLIRT:
+        out.update({"λ": M.lam, "σ²t": M.sig2t, "Σp": np.asarray(M.Sigp).reshape(2, 2, order="F")})
+    if MCMC._model == _lib.MODEL_RTIRT:
+        out["β"] = np.asarray(M.beta).reshape(C.nFeat + 1, 2, order="F")
+    elif M.beta.size:
+        out["β"] = M.beta
+    if MCMC._model == _lib.MODEL_CROSSQR:
+        out["ρ"] = M.rho
+    return out
+
+
+def precis(MCMC: _GibbsBase) -> dict:
+    """Mean / sd / 2.5% / 97.5% of the item-level and structural traces after burn-in (`precis`, src/GibbsRtIrt.pl.jl:545-675,
+    without the MCMCChains ESS/R-hat columns)."""
+    C = MCMC.Cond
+    it = MCMC.Post.item_trace[C.nBurnin * C.nChain:]
+    J = C.nItem
+    names = [f"a[{j+1}]" for j in range(J)] + [f"b[{j+1}]" for j in range(J)] + [f"λ[{j+1}]" for j in range(J)] + \
+            [f"σ²t[{j+1}]" for j in range(J)] + [f"qr[{k+1}]" for k in range(it.shape[1] - 4 * J)]
+    return {"names": names, "mean": it.mean(0), "std": it.std(0, ddof=1), "q025": np.quantile(it, 0.025, axis=0),
+            "q975": np.quantile(it, 0.975, axis=0)}

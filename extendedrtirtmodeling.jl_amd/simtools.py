@@ -1,0 +1,150 @@
+"""Synthetic truth / data generators restating the *distributions* of
+/root/reference/src/SimTools.jl:74-368 (setTruePara*, setData*) with numpy's own generator (Julia's Random.seed! streams
+cannot be reproduced outside Julia).  They define the benchmark and parity-test inputs; recovery metrics getRmse / getBias
+follow src/SimTools.jl:42-45.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .base import InputData, InputPara, SimConditions
+
+
+def _rng(seed):
+    return seed if isinstance(seed, np.random.Generator) else np.random.default_rng(seed)
+
+
+def _truncnorm(g, mu, sd, lo, hi, size):
+    """Truncated(Normal(mu, sd), lo, hi) by rejection (the truncation region has large mass for every call site)."""
+    mu = np.broadcast_to(np.asarray(mu, dtype=np.float64), size).reshape(-1).copy()
+    sd = np.broadcast_to(np.asarray(sd, dtype=np.float64), size).reshape(-1)
+    out = np.empty(mu.size, dtype=np.float64)
+    todo = np.arange(mu.size)
+    while todo.size:
+        x = mu[todo] + sd[todo] * g.standard_normal(todo.size)
+        ok = (x >= lo) & (x <= hi)
+        out[todo[ok]] = x[ok]
+        todo = todo[~ok]
+    return out.reshape(size)
+
+
+def setTrueParaRtIrt(Cond: SimConditions, *, trueStdRa=1.0, trueStdRt=1.0, trueCorr=0.0, seed=1234):
+    """src/SimTools.jl:74-95"""
+    g = _rng(seed)
+    P = InputPara()
+    P.a = _truncnorm(g, 1.0, 0.2, 0.0, np.inf, (Cond.nItem,))
+    P.b = g.normal(0.0, 0.5, Cond.nItem)
+    P.lam = _truncnorm(g, 4.0, 0.2, 0.0, np.inf, (Cond.nItem,))
+    P.sig2t = np.exp(g.normal(np.log(0.3), 0.2, Cond.nItem))
+    sd = np.diag([trueStdRa, trueStdRt])
+    P.Sigp = sd @ np.array([[1.0, trueCorr], [trueCorr, 1.0]]) @ sd
+    P.beta = g.standard_normal((Cond.nFeat, 2))
+    return P
+
+
+def setTrueParaMlIrt(Cond: SimConditions, *, seed=1234):
+    """src/SimTools.jl:100-112"""
+    g = _rng(seed)
+    P = InputPara()
+    P.a = _truncnorm(g, 1.0, 0.2, 0.0, np.inf, (Cond.nItem,))
+    P.b = g.normal(0.0, 0.5, Cond.nItem)
+    P.beta = g.standard_normal((Cond.nFeat, 1))
+    return P
+
+
+def _bernoulli_logit(g, eta):
+    return (g.random(eta.shape) < 1.0 / (1.0 + np.exp(-eta))).astype(np.uint8)
+
+
+def setDataRtIrt(Cond: SimConditions, truePara: InputPara, *, seed=4321):
+    """src/SimTools.jl:149-178"""
+    g = _rng(seed)
+    X = g.standard_normal((Cond.nSubj, Cond.nFeat))
+    L = np.linalg.cholesky(np.asarray(truePara.Sigp).reshape(2, 2))
+    subj = X @ np.asarray(truePara.beta).reshape(Cond.nFeat, 2) + g.standard_normal((Cond.nSubj, 2)) @ L.T
+    truePara.theta, truePara.zeta = subj[:, 0], subj[:, 1]
+    Y = _bernoulli_logit(g, truePara.a[None, :] * (truePara.theta[:, None] - truePara.b[None, :]))
+    mut = truePara.lam[None, :] - truePara.zeta[:, None]
+    logT = _truncnorm(g, mut, np.sqrt(truePara.sig2t)[None, :], 0.0, np.inf, mut.shape)   # :169 truncates logT at 0
+    return InputData(Y=Y, X=X, T=np.exp(logT))
+
+
+def setDataMlIrt(Cond: SimConditions, truePara: InputPara, *, seed=4321):
+    """src/SimTools.jl:349-368"""
+    g = _rng(seed)
+    X = np.empty((Cond.nSubj, Cond.nFeat))
+    X[:, 0] = g.random(Cond.nSubj) < 0.5
+    X[:, 1:] = g.standard_normal((Cond.nSubj, Cond.nFeat - 1))
+    truePara.theta = X @ np.asarray(truePara.beta).reshape(Cond.nFeat) + g.standard_normal(Cond.nSubj)
+    Y = _bernoulli_logit(g, truePara.a[None, :] * (truePara.theta[:, None] - truePara.b[None, :]))
+    return InputData(Y=Y, X=X)
+
+
+def setTrueParaRtIrtCross(Cond: SimConditions, *, trueStdRa=1.0, trueStdRt=1.0, seed=1234):
+    """src/SimTools.jl:188-212"""
+    g = _rng(seed)
+    P = InputPara()
+    P.a = _truncnorm(g, 1.0, 0.2, 0.0, np.inf, (Cond.nItem,))
+    P.b = g.normal(0.0, 0.5, Cond.nItem)
+    P.lam = _truncnorm(g, 3.0, 0.5, 0.0, np.inf, (Cond.nItem,))
+    P.sig2t = np.exp(g.normal(np.log(0.3), 0.2, Cond.nItem))
+    P.Sigp = np.diag([trueStdRa ** 2, trueStdRt ** 2])
+    P.rho = g.normal(0.0, 0.2, Cond.nItem)
+    return P
+
+
+def _noise(g, type, size, sd_norm):
+    if type == "norm":
+        return g.normal(0.0, sd_norm, size)
+    if type == "tail":
+        return g.standard_t(5, size)
+    if type == "skew":
+        return g.gamma(0.5, 1.0, size) - 1.0
+    raise ValueError("type must be 'norm', 'tail' or 'skew'")
+
+
+def setDataRtIrtCross(Cond: SimConditions, truePara: InputPara, *, type="norm", seed=4321):
+    """src/SimTools.jl:222-255"""
+    g = _rng(seed)
+    L = np.linalg.cholesky(np.asarray(truePara.Sigp).reshape(2, 2))
+    subj = g.standard_normal((Cond.nSubj, 2)) @ L.T
+    truePara.theta, truePara.zeta = subj[:, 0], subj[:, 1]
+    Y = _bernoulli_logit(g, truePara.a[None, :] * (truePara.theta[:, None] - truePara.b[None, :]))
+    mut = truePara.lam[None, :] - truePara.zeta[:, None] - truePara.theta[:, None] * truePara.rho[None, :]
+    logT = mut + _noise(g, type, mut.shape, 0.3)
+    return InputData(Y=Y, T=np.exp(logT))
+
+
+def setTrueParaRtIrtLatent(Cond: SimConditions, *, trueStdRa=1.0, trueStdRt=1.0, seed=1234):
+    """src/SimTools.jl:260-293 (sigma2_t is not part of the truth for this family)"""
+    g = _rng(seed)
+    P = InputPara()
+    P.a = _truncnorm(g, 1.0, 0.2, 0.0, np.inf, (Cond.nItem,))
+    P.b = g.normal(0.0, 0.5, Cond.nItem)
+    P.lam = _truncnorm(g, 3.0, 0.2, 0.0, np.inf, (Cond.nItem,))
+    P.Sigp = np.diag([trueStdRa ** 2, trueStdRt ** 2])
+    rho = _truncnorm(g, 0.0, 0.5, -1.0, 1.0, (1,))
+    P.beta = np.concatenate([g.normal(0.0, 0.5, Cond.nFeat), rho])
+    return P
+
+
+def setDataRtIrtLatent(Cond: SimConditions, truePara: InputPara, *, type="norm", seed=4321):
+    """src/SimTools.jl:304-343"""
+    g = _rng(seed)
+    truePara.theta = g.standard_normal(Cond.nSubj)
+    X = g.standard_normal((Cond.nSubj, Cond.nFeat))
+    x = np.column_stack([X, truePara.theta])
+    truePara.zeta = x @ truePara.beta + _noise(g, type, Cond.nSubj, 0.3)
+    Y = _bernoulli_logit(g, truePara.a[None, :] * (truePara.theta[:, None] - truePara.b[None, :]))
+    logT = truePara.lam[None, :] - truePara.zeta[:, None] + g.standard_normal((Cond.nSubj, Cond.nItem))
+    return InputData(Y=Y, T=np.exp(logT), X=X)
+
+
+def getRmse(a, b):
+    """src/SimTools.jl:42"""
+    return float(np.sqrt(np.mean((np.asarray(a) - np.asarray(b)) ** 2)))
+
+
+def getBias(a, b):
+    """src/SimTools.jl:43"""
+    return float(np.mean(np.asarray(a) - np.asarray(b)))

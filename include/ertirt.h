@@ -1,0 +1,122 @@
+/*
+ * ertirt.h -- C ABI of libertirt.so, the MI355X (gfx950) Gibbs engine behind the `sample!` path of
+ * ExtendedRtIrtModeling.jl.
+ *
+ * The reference has no FFI: `sample!` is an ordinary Julia method whose loop body calls the draw functions of
+ * src/Draw.pl.jl.  This boundary is therefore created at the `sample!` method level; each entry point names the
+ * reference interface it replaces (paths relative to /root/reference).  The Julia-side binding (ccall) is in
+ * INTEGRATION.md and extendedrtirtmodeling.jl_amd/julia/.
+ *
+ * Conventions: every function returns 0 on success or a negative ERM_ERR_* code; the message is available from
+ * erm_last_error() (thread-local).  All host arrays are owned by the caller, are read/written only during the call,
+ * and use Julia's column-major layout.  The library owns all device memory behind the opaque handle.
+ * A handle is not re-entrant; distinct handles are independent.
+ */
+#ifndef ERTIRT_H
+#define ERTIRT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct erm_engine* erm_handle;
+
+enum {
+    ERM_MODEL_MLIRT = 0,    /* GibbsMlIrt          src/GibbsRtIrt.pl.jl:76-106, sample! :210-257 */
+    ERM_MODEL_RTIRT = 1,    /* GibbsRtIrt          src/GibbsRtIrt.pl.jl:114-146, sample! :278-346 */
+    ERM_MODEL_CROSSQR = 2,  /* GibbsRtIrtCrossQr   src/GibbsRtIrtCross.pl.jl:115-147, sample! :265-325 */
+    ERM_MODEL_LATENTQR = 3  /* GibbsRtIrtLatentQr  src/GibbsRtIrtLatent.pl.jl:105-137, sample! :271-337 */
+};
+enum { ERM_OK = 0, ERM_ERR_ARG = -1, ERM_ERR_HIP = -2, ERM_ERR_STATE = -3, ERM_ERR_NONFINITE = -4, ERM_ERR_NOTRACE = -5, ERM_ERR_NOMEM = -6 };
+enum { ERM_PREC_F32 = 0, ERM_PREC_F64 = 1 };
+enum { ERM_TRACE_SUMMARY = 0, ERM_TRACE_FULL = 1 };
+enum { ERM_TRACE_RA = 0, ERM_TRACE_RT = 1, ERM_TRACE_QR = 2, ERM_TRACE_LOGLIKE = 3 };
+
+/* Mirrors SimConditions / setCond (src/Base.pl.jl:45-62) plus the sample! kwargs
+ * (intercept, itemtype, cov2one: src/GibbsRtIrt.pl.jl:210,278; src/GibbsRtIrtCross.pl.jl:265; src/GibbsRtIrtLatent.pl.jl:271). */
+typedef struct {
+    int32_t model;          /* ERM_MODEL_* */
+    int32_t n_item;         /* Cond.nItem */
+    int64_t n_subj;         /* Cond.nSubj */
+    int32_t n_feat;         /* Cond.nFeat (columns of Data.X; ignored by CrossQr) */
+    int32_t n_iter;         /* Cond.nIter */
+    int32_t n_chain;        /* Cond.nChain: sweep (m,l) of the reference's interleaved loop is trace row m*nChain+l */
+    int32_t n_burnin;       /* Cond.nBurnin (setCond forces round(nIter/2); the host shim does the same) */
+    int32_t intercept;      /* sample!(...; intercept=false) */
+    int32_t one_pl;         /* itemtype == "1pl" */
+    int32_t cov2one;        /* sample!(...; cov2one) */
+    int32_t sigp_mode;      /* LatentQr Sigma_p scale: 0 = reference expression src/Draw.pl.jl:594 (closed form), 1 = reserved */
+    int32_t chain_id;       /* selects an independent random stream (one chain per GPU farms use the rank) */
+    double  q_rt;           /* Cond.qRt */
+    uint64_t seed;
+    int32_t device;         /* HIP device ordinal */
+    int32_t precision;      /* ERM_PREC_F32: fp32 cell arithmetic + fp64 accumulation; ERM_PREC_F64: all fp64 */
+    int32_t trace_mode;     /* ERM_TRACE_FULL keeps theta/zeta(/nu) per sweep (Post.ra/rt/qr); SUMMARY keeps item-level traces + running means */
+    int32_t lanes_per_row;  /* 0 = auto; power of two in [1,64]: lanes that share one subject */
+    int32_t block_threads;  /* 0 = auto */
+    int32_t grid_blocks;    /* 0 = auto */
+    int32_t profile;        /* 1 = bracket every row-pass launch with HIP events (erm_get_timing) */
+    int32_t reserved;
+} erm_config;
+
+/* Mirrors InputPara (src/Base.pl.jl:100-115).  NULL members are skipped.  Shapes:
+ * theta,zeta [nSubj]; a,b,lambda,sig2t,rho [nItem]; sigp [4] = vec(Sigma_p);
+ * beta: MlIrt [nFeat+1], RtIrt [(nFeat+1)*2] = vec(beta), LatentQr [nFeat+2];
+ * nu: LatentQr [nSubj], CrossQr [nSubj*nItem] column-major. */
+typedef struct {
+    double *theta, *a, *b, *zeta, *lambda, *sig2t, *beta, *sigp, *rho, *nu;
+} erm_state;
+
+typedef struct {
+    double run_ms;          /* device time of the last erm_run (HIP events on the engine's stream) */
+    double pass_ms_total;   /* sum of row-pass kernel durations in the last erm_run (profile=1), else 0 */
+    int64_t pass_launches;  /* number of row-pass launches timed */
+    int64_t sweeps;         /* sweeps in the last erm_run */
+    int32_t lanes_per_row, block_threads, grid_blocks, lds_bytes;
+    int32_t cu_count, reserved;
+} erm_timing;
+
+/* Replaces the Gibbs* constructors' allocation of Post and Para (src/GibbsRtIrt.pl.jl:94-104,134-144). */
+int erm_create(const erm_config* cfg, erm_handle* out);
+void erm_destroy(erm_handle h);
+
+/* Replaces InputData (src/Base.pl.jl:67-78): Y 0/1 bytes [nSubj x nItem], logT = log.(T), X [nSubj x nFeat]; column-major.
+ * logT may be NULL for MlIrt; X may be NULL when n_feat == 0 or for CrossQr. */
+int erm_set_data(erm_handle h, const uint8_t* Y, const double* logT, const double* X);
+
+/* Para in / out (setInitialValues: src/GibbsRtIrt.pl.jl:84-93,122-133; Cross :123-134; Latent :113-124). */
+int erm_set_state(erm_handle h, const erm_state* st);
+int erm_get_state(erm_handle h, erm_state* st);
+
+/* The body of `for m in 1:nIter, l in 1:nChain` (src/GibbsRtIrt.pl.jl:221-246, 289-324; Cross :276-302; Latent :282-314):
+ * runs `nsweeps` sweeps continuing from the current state; sweeps fill trace rows in order. */
+int erm_run(erm_handle h, int64_t nsweeps);
+int64_t erm_rows_done(erm_handle h);
+int erm_reset_trace(erm_handle h);   /* forget recorded rows and running means (state is kept) */
+
+/* Post.ra / Post.rt / Post.qr / Post.logLike (src/GibbsRtIrt.pl.jl:35-71; Cross :55-69; Latent :50-64) in Julia layout
+ * [nIter][width][nChain], nIter fastest.  Needs ERM_TRACE_FULL for RA/RT/QR. */
+int64_t erm_trace_width(erm_handle h, int which);
+int erm_get_trace(erm_handle h, int which, double* out);
+/* item-level trace, always kept: out[row][4*nItem + nq] = a, b, lambda, sig2t, small part of qr (row-major) */
+int64_t erm_item_trace_width(erm_handle h);
+int erm_get_item_trace(erm_handle h, double* out);
+
+/* Post.mean (src/GibbsRtIrt.pl.jl:249-254, 327-343): mean over rows >= nBurnin*nChain of everything in erm_state. */
+int erm_get_mean(erm_handle h, erm_state* out);
+int64_t erm_post_count(erm_handle h);   /* number of rows that entered the means */
+
+int erm_get_timing(erm_handle h, erm_timing* out);
+const char* erm_last_error(void);
+const char* erm_version(void);
+
+/* Diagnostics: run a device sampler on n independent streams (stream k = (seed, site, i=k, sweep)); used by the parity
+ * tests to compare the device restatement of each sampler with the oracle.  which: 0 uniform, 1 normal, 2 expo,
+ * 3 PG(1, par0), 4 IG(par0, par1), 5 TN(par0, par1; 0, inf), 6 Gamma(par0), 7 PG mixture weight(par0), 8 QR weight(par0, par1). */
+int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32_t site, uint32_t sweep, int64_t n,
+                     const double* par0, const double* par1, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+/*
+ * oracle/orc_rng.h -- TEST INFRASTRUCTURE ONLY (CPU oracle; "parity unpinned", see erm_oracle.c header).
+ *
+ * Counter-based random streams and the scalar samplers behind every full conditional of
+ * /root/reference/src/Draw.pl.jl.  The reference takes these from un-vendored Julia packages
+ * (PolyaGammaSamplers 0.1, Distributions 0.25, Random stdlib; Project.toml:14-15,37-38) whose
+ * sources are absent from /root/reference, and Julia's Xoshiro stream cannot be reproduced
+ * outside Julia.  They are therefore restated from the published algorithms:
+ *
+ *   Philox4x32-10      Salmon, Moraes, Dror, Shaw (SC'11); constants as in Random123 / rocRAND.
+ *   PG(1,c)            Polson, Scott & Windle (2013) Alg. for J*(1,z), truncation t = 0.64
+ *                      (call site src/Draw.pl.jl:38, PolyaGammaPSWSampler(1, eta)).
+ *   IG(mu,lambda)      Michael, Schucany & Haas (1976)   (call sites src/Draw.pl.jl:312,335)
+ *   TN(m,s;0,inf)      rejection from N(0,1) / Robert (1995) exponential tail
+ *                      (call sites src/Draw.pl.jl:91,218,248)
+ *   Gamma(shape>=1)    Marsaglia & Tsang (2000)          (InverseGamma: src/Draw.pl.jl:260,286,546,596)
+ *
+ * A "stream" is the sequence of 32-bit words philox(key; c0=i, c1=j, c2=sweep,
+ * c3 = site<<24 | chain<<16 | k) for k = 0,1,2,...; words are consumed strictly in order, so the
+ * HIP kernels (which restate the same definitions on the device) consume the same variates for
+ * the same (site, i, j, sweep) regardless of launch geometry.
+ */
+#ifndef ORC_RNG_H
+#define ORC_RNG_H
+#include <stdint.h>
+#include <math.h>
+
+#define ORC_PI 3.14159265358979323846
+
+/* draw-site ids (shared by oracle and device; part of the sampling specification) */
+enum {
+    ORC_SITE_OMEGA = 1, ORC_SITE_THETA = 2, ORC_SITE_ZETA = 3, ORC_SITE_NU = 4,
+    ORC_SITE_B = 5, ORC_SITE_A = 6, ORC_SITE_LAMBDA = 7, ORC_SITE_SIG2T = 8,
+    ORC_SITE_BETA = 9, ORC_SITE_SIGP = 10, ORC_SITE_RHO = 11, ORC_SITE_TEST = 15
+};
+
+static inline void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct {
+    uint32_t key[2];
+    uint32_t c0, c1, c2, c3base;
+    uint32_t k;      /* next block index */
+    uint32_t buf[4];
+    int pos;         /* next unread word in buf (4 = empty) */
+} orc_stream;
+
+static inline orc_stream orc_stream_make(uint64_t seed, int chain, int site, uint32_t i, uint32_t j, uint32_t sweep)
+{
+    orc_stream s;
+    s.key[0] = (uint32_t)seed; s.key[1] = (uint32_t)(seed >> 32);
+    s.c0 = i; s.c1 = j; s.c2 = sweep;
+    s.c3base = ((uint32_t)site << 24) | (((uint32_t)chain & 0xFFu) << 16);
+    s.k = 0; s.pos = 4;
+    return s;
+}
+
+static inline uint32_t orc_u32(orc_stream* s)
+{
+    if (s->pos == 4) {
+        uint32_t ctr[4] = { s->c0, s->c1, s->c2, s->c3base | (s->k & 0xFFFFu) };
+        orc_philox4x32_10(ctr, s->key, s->buf);
+        s->k++; s->pos = 0;
+    }
+    return s->buf[s->pos++];
+}
+
+/* U(0,1): (x + 1/2) 2^-32, never 0 or 1.  (The fp32 device path uses ((x>>8)+1/2) 2^-24, the
+ * same value rounded down to 24 bits.) */
+static inline double orc_unif(orc_stream* s) { return ((double)orc_u32(s) + 0.5) * (1.0 / 4294967296.0); }
+static inline double orc_expo(orc_stream* s) { return -log(orc_unif(s)); }
+/* N(0,1): Box-Muller cosine branch, two words per variate (the sine partner is discarded). */
+static inline double orc_normal(orc_stream* s)
+{
+    double u1 = orc_unif(s), u2 = orc_unif(s);
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * ORC_PI * u2);
+}
+
+/* log of the standard normal cdf, stable in both tails */
+static inline double orc_log_pnorm(double x)
+{
+    if (x > 0.0) return log1p(-0.5 * erfc(x * M_SQRT1_2));
+    return log(0.5 * erfc(-x * M_SQRT1_2));
+}
+
+/* ---- Inverse Gaussian IG(mu, lambda), Michael-Schucany-Haas; the smaller root is written as
+ * mu * (2 sqrt(lambda w) / (s + w))^2 with w = mu*y, s = sqrt(w (4 lambda + w)), which is
+ * algebraically mu + mu/(2 lambda) (w - sqrt(w (4 lambda + w))) but free of cancellation. */
+static inline double orc_invgauss(orc_stream* s, double mu, double lambda)
+{
+    double n = orc_normal(s);
+    double w = mu * n * n;
+    double sq = sqrt(w) * sqrt(4.0 * lambda + w);
+    double q = 2.0 * sqrt(lambda * w) / (sq + w);
+    double x1 = mu * q * q;
+    double u = orc_unif(s);
+    return (u >= mu / (mu + x1)) ? mu * mu / x1 : x1;
+}
+
+/* ---- Polya-Gamma PG(1, c) ---- */
+#define ORC_PG_T 0.64
+
+static inline double orc_pg_an(int n, double x)
+{
+    double kk = (n + 0.5) * ORC_PI;
+    if (x > ORC_PG_T) return kk * exp(-0.5 * kk * kk * x);
+    double h = 2.0 / (ORC_PI * x);
+    return kk * h * sqrt(h) * exp(-2.0 * (n + 0.5) * (n + 0.5) / x);
+}
+
+/* probability that the proposal comes from the exponential tail: p/(p+q) */
+static inline double orc_pg_mass_texpon(double z)
+{
+    const double t = ORC_PG_T;
+    double fz = 0.125 * ORC_PI * ORC_PI + 0.5 * z * z;
+    double b = sqrt(1.0 / t) * (t * z - 1.0);
+    double a = -sqrt(1.0 / t) * (t * z + 1.0);
+    double x0 = log(fz) + fz * t;
+    double xb = x0 - z + orc_log_pnorm(b);
+    double xa = x0 + z + orc_log_pnorm(a);
+    double qdivp = 4.0 / ORC_PI * (exp(xb) + exp(xa));
+    return 1.0 / (1.0 + qdivp);
+}
+
+/* IG(1/z, 1) truncated to (0, t) */
+static inline double orc_pg_rtigauss(orc_stream* s, double z)
+{
+    const double t = ORC_PG_T;
+    double x;
+    if (z < 1.0 / t) {
+        double alpha;
+        do {
+            double e1, e2;
+            do { e1 = orc_expo(s); e2 = orc_expo(s); } while (e1 * e1 > 2.0 * e2 / t);
+            x = 1.0 + e1 * t;
+            x = t / (x * x);
+            alpha = exp(-0.5 * z * z * x);
+        } while (orc_unif(s) > alpha);
+    } else {
+        double mu = 1.0 / z;
+        do { x = orc_invgauss(s, mu, 1.0); } while (x > t);
+    }
+    return x;
+}
+
+static inline double orc_pg1(orc_stream* s, double c)
+{
+    const double t = ORC_PG_T;
+    double z = 0.5 * fabs(c);
+    double fz = 0.125 * ORC_PI * ORC_PI + 0.5 * z * z;
+    double r = orc_pg_mass_texpon(z);
+    for (;;) {
+        double x;
+        if (orc_unif(s) < r) x = t + orc_expo(s) / fz;
+        else x = orc_pg_rtigauss(s, z);
+        double S = orc_pg_an(0, x);
+        double y = orc_unif(s) * S;
+        int n = 0;
+        for (;;) {
+            ++n;
+            if (n & 1) { S -= orc_pg_an(n, x); if (y <= S) return 0.25 * x; }
+            else       { S += orc_pg_an(n, x); if (y > S) break; }
+            if (n > 200) return 0.25 * x; /* unreachable guard */
+        }
+    }
+}
+
+/* ---- truncated normal on (0, inf): TN(m, s; 0, inf) ---- */
+static inline double orc_truncnorm0(orc_stream* s, double m, double sd)
+{
+    double alpha = -m / sd, z;
+    if (alpha <= 0.0) {
+        do { z = orc_normal(s); } while (z < alpha);
+    } else {
+        double lam = 0.5 * (alpha + sqrt(alpha * alpha + 4.0));
+        for (;;) {
+            z = alpha + orc_expo(s) / lam;
+            double u = orc_unif(s);
+            if (u <= exp(-0.5 * (z - lam) * (z - lam))) break;
+        }
+    }
+    return m + sd * z;
+}
+
+/* ---- Gamma(shape >= 1, scale 1), Marsaglia-Tsang without the squeeze ---- */
+static inline double orc_gamma(orc_stream* s, double shape)
+{
+    double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x, v;
+        do { x = orc_normal(s); v = 1.0 + c * x; } while (v <= 0.0);
+        v = v * v * v;
+        double u = orc_unif(s);
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+    }
+}
+/* InverseGamma(shape, scale) in Distributions.jl's parametrisation: scale / Gamma(shape,1) */
+static inline double orc_invgamma(orc_stream* s, double shape, double scale) { return scale / orc_gamma(s, shape); }
+static inline double orc_chisq(orc_stream* s, double k) { return 2.0 * orc_gamma(s, 0.5 * k); }
+
+#endif
