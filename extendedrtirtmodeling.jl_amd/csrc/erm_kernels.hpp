@@ -77,7 +77,7 @@ constexpr double LOG_2PI = 1.8378770664093454836;
 // Row pass.  blockDim.x = 64 * nWaves.  Dynamic LDS: item arrays (real), structural scalars, per-wave accumulators.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MODEL, typename real, int PHASE>
-__global__ void __launch_bounds__(1024) pass_kernel(PassArgs<real> A)
+__global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(PassArgs<real> A)
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;

@@ -16,6 +16,8 @@
 
 namespace erm {
 
+constexpr int MAX_TRIES = 4096;   // bound on every rejection loop: a non-finite input yields NaN (caught by the tiny step's check), never a hang
+
 enum Site : uint32_t {
     SITE_OMEGA = 1, SITE_THETA = 2, SITE_ZETA = 3, SITE_NU = 4, SITE_B = 5, SITE_A = 6,
     SITE_LAMBDA = 7, SITE_SIG2T = 8, SITE_BETA = 9, SITE_SIGP = 10, SITE_RHO = 11, SITE_TEST = 15
@@ -165,17 +167,20 @@ template <typename real> __device__ __forceinline__ real pg_rtigauss(Stream& s, 
     const real t = real(0.64);
     real x;
     if (z < real(1) / t) {
+        // every rejection loop is bounded (MAX_TRIES) so that a non-finite input can never hang a wave
         real alpha;
+        int tries = 0;
         do {
             real e1, e2;
-            do { e1 = expo<real>(s); e2 = expo<real>(s); } while (e1 * e1 > real(2) * e2 / t);
+            do { e1 = expo<real>(s); e2 = expo<real>(s); } while (e1 * e1 > real(2) * e2 / t && ++tries < MAX_TRIES);
             x = real(1) + e1 * t;
             x = t / (x * x);
             alpha = r_exp(real(-0.5) * z * z * x);
-        } while (uniform<real>(s) > alpha);
+        } while (uniform<real>(s) > alpha && ++tries < MAX_TRIES);
     } else {
         const real mu = real(1) / z;
-        do { x = invgauss<real>(s, mu, real(1)); } while (x > t);
+        int tries = 0;
+        do { x = invgauss<real>(s, mu, real(1)); } while (x > t && ++tries < MAX_TRIES);
     }
     return x;
 }
@@ -187,7 +192,7 @@ template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c)
     const real z = real(0.5) * r_abs(c);
     const real fz = real(0.125) * PI * PI + real(0.5) * z * z;
     const real r = pg_mass_texpon<real>(z);
-    for (;;) {
+    for (int tries = 0;; ++tries) {
         real x;
         if (uniform<real>(s) < r) x = t + expo<real>(s) / fz;
         else x = pg_rtigauss<real>(s, z);
@@ -200,6 +205,7 @@ template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c)
             else       { S += pg_an<real>(n, x); if (y > S) break; }
             if (n > 200) return real(0.25) * x;
         }
+        if (tries >= MAX_TRIES) return real(0.25) * x;
     }
 }
 
@@ -208,14 +214,15 @@ __device__ __forceinline__ double truncnorm0(Stream& s, double m, double sd)
 {
     const double alpha = -m / sd;
     double z;
+    int tries = 0;
     if (alpha <= 0.0) {
-        do { z = normal<double>(s); } while (z < alpha);
+        do { z = normal<double>(s); } while (z < alpha && ++tries < MAX_TRIES);
     } else {
         const double lam = 0.5 * (alpha + sqrt(alpha * alpha + 4.0));
         for (;;) {
             z = alpha + expo<double>(s) / lam;
             const double u = uniform<double>(s);
-            if (u <= exp(-0.5 * (z - lam) * (z - lam))) break;
+            if (u <= exp(-0.5 * (z - lam) * (z - lam)) || ++tries >= MAX_TRIES) break;
         }
     }
     return m + sd * z;
@@ -224,12 +231,13 @@ __device__ __forceinline__ double truncnorm0(Stream& s, double m, double sd)
 __device__ __forceinline__ double gamma_mt(Stream& s, double shape)
 {
     const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-    for (;;) {
+    for (int tries = 0;; ++tries) {
         double x, v;
-        do { x = normal<double>(s); v = 1.0 + c * x; } while (v <= 0.0);
+        do { x = normal<double>(s); v = 1.0 + c * x; } while (v <= 0.0 && ++tries < MAX_TRIES);
         v = v * v * v;
         const double u = uniform<double>(s);
         if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+        if (tries >= MAX_TRIES) return __builtin_nan("");
     }
 }
 __device__ __forceinline__ double invgamma(Stream& s, double shape, double scale) { return scale / gamma_mt(s, shape); }

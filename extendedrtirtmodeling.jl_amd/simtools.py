@@ -15,17 +15,18 @@ def _rng(seed):
 
 
 def _truncnorm(g, mu, sd, lo, hi, size):
-    """Truncated(Normal(mu, sd), lo, hi) by rejection (the truncation region has large mass for every call site)."""
-    mu = np.broadcast_to(np.asarray(mu, dtype=np.float64), size).reshape(-1).copy()
-    sd = np.broadcast_to(np.asarray(sd, dtype=np.float64), size).reshape(-1)
-    out = np.empty(mu.size, dtype=np.float64)
-    todo = np.arange(mu.size)
-    while todo.size:
-        x = mu[todo] + sd[todo] * g.standard_normal(todo.size)
-        ok = (x >= lo) & (x <= hi)
-        out[todo[ok]] = x[ok]
-        todo = todo[~ok]
-    return out.reshape(size)
+    """Truncated(Normal(mu, sd), lo, hi) by inverse cdf, evaluated through whichever tail keeps it well conditioned
+    (plain rejection never terminates when the truncation region is far in a tail, e.g. logT > 0 with lambda - zeta << 0)."""
+    from scipy.special import ndtr, ndtri
+    mu = np.broadcast_to(np.asarray(mu, dtype=np.float64), size)
+    sd = np.broadcast_to(np.asarray(sd, dtype=np.float64), size)
+    a, b = (lo - mu) / sd, (hi - mu) / sd
+    u = g.random(size)
+    upper = a > 0                                   # work with survival probabilities when the region is in the upper tail
+    pa, pb = np.where(upper, ndtr(-a), ndtr(a)), np.where(upper, ndtr(-b), ndtr(b))
+    q = pa + u * (pb - pa)
+    z = np.where(upper, -ndtri(q), ndtri(q))
+    return np.clip(mu + sd * z, lo, hi)
 
 
 def setTrueParaRtIrt(Cond: SimConditions, *, trueStdRa=1.0, trueStdRt=1.0, trueCorr=0.0, seed=1234):

@@ -203,5 +203,8 @@ def max_rel_err(res, floor=1e-6):
         e.append(rel_err(res["dev_rt"], res["orc"]["rt"], floor).max())
     if res["model"] != "crossqr":
         e.append(rel_err(res["dev_qr"], res["orc"]["qr"], floor).max())
+    else:
+        J = res["orc"]["qr"].shape[1] - 4
+        e.append(rel_err(res["dev"]["item"][:, 4 * J:], res["orc"]["qr"], floor).max())
     e.append(rel_err(res["dev_ll"], res["orc"]["ll"], floor).max())
     return float(max(e))

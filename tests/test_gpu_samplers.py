@@ -1,0 +1,79 @@
+"""Device samplers vs the oracle's: same (seed, site, i, sweep) stream => same variate.
+fp64: agreement to rounding (1e-12 relative); fp32: the fp32 evaluation of the same algorithm (tolerances stated per test)."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+
+N = 200_000
+
+
+def _dev(which, n, p0=None, p1=None, precision=1, **kw):
+    L = pu.ge.load_package()._lib
+    return L.debug_sample(which, n, p0, p1, precision=precision, **kw)
+
+
+@pytest.mark.parametrize("which,name", [(0, "uniform"), (1, "normal"), (2, "expo")])
+def test_basic_variates_f64(which, name):
+    d, o = _dev(which, N), pu.orc_sample(which, N)
+    assert np.max(np.abs(d - o)) < 1e-12, name
+
+
+def test_uniform_f32_is_rounded_f64():
+    d, o = _dev(0, N, precision=0), pu.orc_sample(0, N)
+    assert np.max(np.abs(d - o)) <= 2.0 ** -24
+    assert d.min() > 0.0 and d.max() < 1.0
+
+
+def test_pg_mixture_weight():
+    z = np.linspace(0.0, 12.0, 4001)
+    o = pu.orc_sample(7, z.size, z)
+    assert np.max(np.abs(_dev(7, z.size, z) - o)) < 1e-12
+    assert np.max(np.abs(_dev(7, z.size, z, precision=0) - o)) < 2e-5     # fp32 evaluation of exp(x0 -+ z + log Phi)
+
+
+def test_pg1_f64_matches_oracle():
+    g = np.random.default_rng(0)
+    c = g.normal(0, 2.5, N)
+    d, o = _dev(3, N, c), pu.orc_sample(3, N, c)
+    assert np.max(np.abs(d - o) / o) < 1e-10
+
+
+def test_pg1_f32_matches_oracle_except_rare_flips():
+    g = np.random.default_rng(1)
+    c = g.normal(0, 2.5, N)
+    d, o = _dev(3, N, c, precision=0), pu.orc_sample(3, N, c)
+    rel = np.abs(d - o) / o
+    assert np.mean(rel > 1e-4) < 2e-4          # accept/reject decisions flip only where fp32 rounding crosses a threshold
+    assert np.median(rel) < 1e-6
+    # and the fp32 draws still have the right moments
+    for cc in (0.0, 1.0, 4.0):
+        x = _dev(3, N, np.full(N, cc), precision=0, sweep=3)
+        m = 0.25 if cc == 0 else np.tanh(cc / 2) / (2 * cc)
+        v = 1 / 24 if cc == 0 else (np.sinh(cc) - cc) / (4 * cc ** 3 * np.cosh(cc / 2) ** 2)
+        assert abs(x.mean() - m) < 5 * np.sqrt(v / N)
+
+
+def test_invgauss_and_qr_weight():
+    g = np.random.default_rng(2)
+    mu, lam = np.exp(g.normal(0, 1.5, N)), np.exp(g.normal(0, 1, N))
+    d, o = _dev(4, N, mu, lam), pu.orc_sample(4, N, mu, lam)
+    assert np.max(np.abs(d - o) / o) < 1e-10
+    d32 = _dev(4, N, mu, lam, precision=0)
+    assert np.mean(np.abs(d32 - o) / o > 1e-3) < 1e-3
+    pa, pb = np.abs(g.normal(0, 1, N)) + 1e-12, np.full(N, 1.7)
+    d, o = _dev(8, N, pa, pb), pu.orc_sample(8, N, pa, pb)
+    assert np.max(np.abs(d - o) / o) < 1e-10
+
+
+def test_item_level_samplers():
+    g = np.random.default_rng(3)
+    m, s = g.normal(0.5, 2, N), np.exp(g.normal(-1, 1, N))
+    d, o = _dev(5, N, m, s), pu.orc_sample(5, N, m, s)
+    assert np.max(np.abs(d - o) / (np.abs(m) + s)) < 1e-12      # m + s*z cancels near the truncation point
+    assert d.min() > 0
+    sh = np.exp(g.uniform(0, 13, 20000))        # shapes 1 .. 4e5 (N/2 and 3N/2 at the benchmark sizes)
+    d, o = _dev(6, sh.size, sh), pu.orc_sample(6, sh.size, sh)
+    assert np.max(np.abs(d - o) / o) < 1e-10
