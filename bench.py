@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- Gibbs sweeps/s of the MI355X engine on BASELINE.json's workload.
+
+A "step" is ONE Gibbs sweep (every full conditional of one `for m, l` iteration of sample!) over one synthetic data set
+that is already resident in HBM.  Default workload: GibbsRtIrt, nSubj=100000, nItem=50, nFeat=3 (BASELINE.json configs[2],
+the configuration the north-star target is quoted on); data per setDataRtIrt's distributions, fixed seed.
+N GPUs = N independent chains (one process per GPU, chain_id = rank, no data-path collective): "scaling": "weak".
+After the timed region the ranks all-reduce their posterior summaries over RCCL (timed separately, reported as gather_ms).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (the fused row pass): algorithmic bytes per launch / mean launch duration measured live with
+                  HIP events on the engine's stream, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (kind "port": fp64 C restatement of the reference's un-fused schedule, 1 thread) timed on this
+                  host for a bounded number of sweeps of the SAME workload.  The reference itself is Julia and cannot run here.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+ALGO_BYTES = {"mlirt": 9, "rtirt": 13, "latentqr": 13, "crossqr": 29}   # fp32 matrices, Y as 1 byte
+HBM_PEAK_GBS = 8000.0                                                     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_data(pkg, model, N, J, F, seed):
+    Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=F, nIter=10, nChain=1, qRt=0.85)
+    g = np.random.default_rng(seed)
+    if model == "mlirt":
+        tp = pkg.setTrueParaMlIrt(Cond, seed=g); D = pkg.setDataMlIrt(Cond, tp, seed=g)
+        return D.Y, None, D.X
+    if model == "rtirt":
+        tp = pkg.setTrueParaRtIrt(Cond, seed=g); D = pkg.setDataRtIrt(Cond, tp, seed=g)
+        return D.Y, D.logT, D.X
+    if model == "crossqr":
+        tp = pkg.setTrueParaRtIrtCross(Cond, seed=g); D = pkg.setDataRtIrtCross(Cond, tp, seed=g)
+        return D.Y, D.logT, None
+    tp = pkg.setTrueParaRtIrtLatent(Cond, seed=g); D = pkg.setDataRtIrtLatent(Cond, tp, seed=g)
+    return D.Y, D.logT, D.X
+
+
+def init_state(model, N, J, F, rank):
+    g = np.random.default_rng([99, rank])
+    st = dict(theta=g.standard_normal(N))
+    if model != "mlirt":
+        st.update(zeta=g.standard_normal(N), sigp=np.eye(2))
+    if model == "mlirt":
+        st["beta"] = g.standard_normal(F + 1)
+    elif model == "rtirt":
+        st["beta"] = g.standard_normal((F + 1, 2))
+    elif model == "latentqr":
+        st["beta"] = g.standard_normal(F + 2)
+    else:
+        st["rho"] = g.standard_normal(J)
+    return st
+
+
+def cpu_baseline(model, Y, logT, X, st, sweeps):
+    """Oracle (kind 'port'), single thread, on the same workload; bounded number of sweeps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_util as pu
+    op = pu.OracleProblem(model, Y, logT, X, st, qRt=0.85, cov2one=(model != "latentqr"))
+    op.run(1)                       # warm-up sweep (page in, first omega)
+    t0 = time.perf_counter()
+    op.run(sweeps)
+    dt = time.perf_counter() - t0
+    return dt / sweeps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="rtirt", choices=list(ALGO_BYTES))
+    ap.add_argument("--nsubj", type=int, default=100000)
+    ap.add_argument("--nitem", type=int, default=50)
+    ap.add_argument("--nfeat", type=int, default=3)
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--trace", default="full", choices=["full", "summary"])
+    ap.add_argument("--lanes-per-row", type=int, default=0)
+    ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--grid-blocks", type=int, default=0)
+    ap.add_argument("--cpu-sweeps", type=int, default=-1, help="oracle sweeps for cpu_baseline (-1 = auto ~15 s, 0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket row-pass launches with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    ge.build_hip()
+    pkg = ge.load_package()
+    L = pkg._lib
+    model, N, J, F = args.model, args.nsubj, args.nitem, args.nfeat
+    Y, logT, X = make_data(pkg, model, N, J, F, seed=1234)
+    st = init_state(model, N, J, F, rank)
+    rows = args.warmup + args.steps
+    eng = L.Engine(model=getattr(L, "MODEL_" + model.upper()), n_item=J, n_subj=N, n_feat=0 if X is None else F, n_iter=rows, n_chain=1,
+                   n_burnin=args.warmup, cov2one=int(model != "latentqr"), q_rt=0.85, seed=1234, chain_id=rank, device=local_rank,
+                   precision=L.PREC_F32 if args.precision == "f32" else L.PREC_F64,
+                   trace_mode=L.TRACE_FULL if args.trace == "full" else L.TRACE_SUMMARY, lanes_per_row=args.lanes_per_row,
+                   block_threads=args.block_threads, grid_blocks=args.grid_blocks, profile=0 if args.no_profile else 1)
+    eng.set_data(Y, logT, X)       # inputs resident in HBM from here on
+    eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in st.items()})
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        eng.run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(args.steps)            # erm_run returns after hipStreamSynchronize on the engine's stream
+    barrier()
+    dt = time.perf_counter() - t0
+    tm = eng.timing()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # posterior-summary gather over RCCL (outside the timed region; this is the only collective of the path)
+    gather_ms = None
+    if dist is not None:
+        mean = eng.get_mean()
+        P = pkg.InputPara(theta=mean["theta"], a=mean["a"], b=mean["b"])
+        for k_src, k_dst in (("zeta", "zeta"), ("lambda_", "lam"), ("sig2t", "sig2t"), ("beta", "beta"), ("sigp", "Sigp"), ("rho", "rho")):
+            if mean.get(k_src) is not None:
+                setattr(P, k_dst, mean[k_src])
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        pkg.parallel.gather_posterior_summaries(P, eng.post_count, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        cells = float(N) * J
+        value = cells * args.steps * world / dt
+        out = {
+            "metric": "Gibbs cell-updates/s (nSubj x nItem x sweeps/s)", "value": value, "unit": "cell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"Gibbs{ {'mlirt': 'MlIrt', 'rtirt': 'RtIrt', 'latentqr': 'RtIrtLatentQr', 'crossqr': 'RtIrtCrossQr'}[model] } "
+                                   f"nSubj={N} nItem={J} nFeat={F} nChain=1 per GPU (BASELINE.json configs[2])",
+                       "chains": world, "trace": args.trace, "lanes_per_row": tm["lanes_per_row"], "block_threads": tm["block_threads"],
+                       "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"]},
+            "sweeps_per_s": args.steps * world / dt, "device_ms_per_step": tm["run_ms"] / args.steps,
+        }
+        if gather_ms is not None:
+            out["gather_ms"] = gather_ms
+        if tm["pass_launches"] > 0:
+            per_launch_s = tm["pass_ms_total"] / tm["pass_launches"] * 1e-3
+            launches_per_sweep = 2 if model == "crossqr" else 1
+            algo = ALGO_BYTES[model] * cells / launches_per_sweep
+            ach = algo / per_launch_s / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "kernel": "pass_kernel (fused row pass)", "launch_us": per_launch_s * 1e6,
+                               "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"])}
+        ncpu = args.cpu_sweeps
+        if ncpu != 0:
+            if ncpu < 0:
+                ncpu = max(2, int(round(15.0 / (cells * 2.6e-7))))      # ~0.26 us per cell-update on one host core
+            sec = cpu_baseline(model, Y, logT, X, st, ncpu)
+            out["cpu_baseline"] = {"value": cells / sec, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+                                   "sample": f"{ncpu} sweeps of the same workload after 1 warm-up sweep; oracle/erm_oracle.c (fp64, "
+                                             f"reference's un-fused schedule); proxy for Julia sample! (Julia unavailable)",
+                                   "s_per_sweep": sec}
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -690,9 +690,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
         }
     }
     if (tid == 0) {
-        bool bad = false;
-        for (int e = 0; e < 4 * J; ++e) bad |= !(fabs(par[e]) < 1e300);
-        if (bad) T.ctl->err = 1u;
+        for (int e = 0; e < par_size(J); ++e)
+            if (!(fabs(par[e]) < 1e300) && T.ctl->err == 0u) T.ctl->err = 1u + (uint32_t)e;   // first non-finite entry of the parameter block
         if (STEP == 0) { T.ctl->sweep = sweep; T.ctl->row = row; }
     }
 }

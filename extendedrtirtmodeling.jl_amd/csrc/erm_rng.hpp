@@ -4,7 +4,8 @@
 //   stream(site, i, j, sweep) = words of Philox4x32-10(key = seed; ctr = {i, j, sweep, site<<24 | chain<<16 | k}),
 //   k = 0,1,2,..., consumed strictly in order.  Because draws are addressed by (site, i, j, sweep) and not by
 //   thread id, results do not depend on launch geometry.
-//   uniform: fp64 (x + 1/2) 2^-32; fp32 ((x >> 8) + 1/2) 2^-24 (the same value rounded to 24 bits)
+//   uniform: fp64 (x + 1/2) 2^-32; fp32 ((x >> 9) + 1/2) 2^-23 (the same value truncated to 23 bits: every value is exactly
+//            representable in fp32, lies strictly inside (0,1) and never makes cospi(2u) vanish)
 //   expo   : -log(u);  normal: sqrt(-2 log u1) cos(2 pi u2) (two words per variate)
 //   PG(1,c): Polson-Scott-Windle / Devroye alternating-series sampler, t = 0.64
 //            (replaces PolyaGammaPSWSampler(1, eta) at /root/reference/src/Draw.pl.jl:38)
@@ -97,7 +98,7 @@ struct Stream {
 
 template <typename real> __device__ __forceinline__ real uniform(Stream& s);
 template <> __device__ __forceinline__ double uniform<double>(Stream& s) { return ((double)s.next() + 0.5) * (1.0 / 4294967296.0); }
-template <> __device__ __forceinline__ float uniform<float>(Stream& s) { return ((float)(s.next() >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+template <> __device__ __forceinline__ float uniform<float>(Stream& s) { return ((float)(s.next() >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 template <typename real> __device__ __forceinline__ real expo(Stream& s) { return -r_log(uniform<real>(s)); }
 
@@ -120,7 +121,8 @@ template <typename real> __device__ __forceinline__ real invgauss(Stream& s, rea
     const real nrm = normal<real>(s);
     const real w = mu * nrm * nrm;
     const real sq = r_sqrt(w) * r_sqrt(real(4) * lambda + w);
-    const real q = real(2) * r_sqrt(lambda * w) / (sq + w);
+    const real den = sq + w;
+    const real q = den > real(0) ? real(2) * r_sqrt(lambda * w) / den : real(1);   // w -> 0: x1 -> mu
     const real x1 = mu * q * q;
     const real u = uniform<real>(s);
     return (u >= mu / (mu + x1)) ? mu * mu / x1 : x1;

@@ -356,7 +356,13 @@ template <typename real> struct Engine : EngineBase {
         if (hi > lo) post_rows += hi - lo;
         rows_done += nsweeps;
         sweeps_total += (uint32_t)nsweeps;
-        if (back.err) return fail(ERM_ERR_NONFINITE, "non-finite item parameter encountered");
+        if (back.err) {
+            const int e = (int)back.err - 1;
+            const char* names[] = {"a", "b", "lambda", "sig2t", "rho"};
+            std::string what = e < 5 * J ? std::string(names[e / J]) + "[" + std::to_string(e % J) + "]"
+                             : (e < 5 * J + 4 ? "Sigp[" + std::to_string(e - 5 * J) + "]" : "beta[" + std::to_string(e - 5 * J - 4) + "]");
+            return fail(ERM_ERR_NONFINITE, "non-finite parameter " + what + " at sweep " + std::to_string(back.sweep));
+        }
         return 0;
     }
 

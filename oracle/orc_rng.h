@@ -79,8 +79,8 @@ static inline uint32_t orc_u32(orc_stream* s)
     return s->buf[s->pos++];
 }
 
-/* U(0,1): (x + 1/2) 2^-32, never 0 or 1.  (The fp32 device path uses ((x>>8)+1/2) 2^-24, the
- * same value rounded down to 24 bits.) */
+/* U(0,1): (x + 1/2) 2^-32, never 0 or 1.  (The fp32 device path uses ((x>>9)+1/2) 2^-23, the
+ * same value truncated to 23 bits so that it is exact in fp32.) */
 static inline double orc_unif(orc_stream* s) { return ((double)orc_u32(s) + 0.5) * (1.0 / 4294967296.0); }
 static inline double orc_expo(orc_stream* s) { return -log(orc_unif(s)); }
 /* N(0,1): Box-Muller cosine branch, two words per variate (the sine partner is discarded). */
@@ -105,7 +105,8 @@ static inline double orc_invgauss(orc_stream* s, double mu, double lambda)
     double n = orc_normal(s);
     double w = mu * n * n;
     double sq = sqrt(w) * sqrt(4.0 * lambda + w);
-    double q = 2.0 * sqrt(lambda * w) / (sq + w);
+    double den = sq + w;
+    double q = den > 0.0 ? 2.0 * sqrt(lambda * w) / den : 1.0; /* w -> 0: x1 -> mu */
     double x1 = mu * q * q;
     double u = orc_unif(s);
     return (u >= mu / (mu + x1)) ? mu * mu / x1 : x1;

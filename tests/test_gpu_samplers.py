@@ -23,7 +23,7 @@ def test_basic_variates_f64(which, name):
 
 def test_uniform_f32_is_rounded_f64():
     d, o = _dev(0, N, precision=0), pu.orc_sample(0, N)
-    assert np.max(np.abs(d - o)) <= 2.0 ** -24
+    assert np.max(np.abs(d - o)) <= 2.0 ** -23
     assert d.min() > 0.0 and d.max() < 1.0
 
 
