@@ -35,13 +35,15 @@ __host__ __device__ inline int par_off_sigp(int J) { return 5 * J; }
 __host__ __device__ inline int par_off_beta(int J) { return 5 * J + 4; }
 __host__ __device__ inline int par_size(int J) { return 5 * J + 4 + 2 * PMAX; }
 
-// data constants (fp64): K0[J], m[J] (column means of logT), csq[J] (sum of squared centred logT), muLam, sdLam, XtX[PMAX*PMAX]
+// data constants (fp64): K0[J], m[J] (column means of logT), csq[J] (sum of squared centred logT), muLam, sdLam,
+// XtX[PMAX*PMAX] = x'x with x = [1 X] (iteration-invariant, src/Draw.pl.jl:383-386 recomputes it every sweep), XtXinv[PMAX*PMAX]
 __host__ __device__ inline int cst_off_k0(int) { return 0; }
 __host__ __device__ inline int cst_off_m(int J) { return J; }
 __host__ __device__ inline int cst_off_csq(int J) { return 2 * J; }
 __host__ __device__ inline int cst_off_mu(int J) { return 3 * J; }
 __host__ __device__ inline int cst_off_xtx(int J) { return 3 * J + 2; }
-__host__ __device__ inline int cst_size(int J) { return 3 * J + 2 + PMAX * PMAX; }
+__host__ __device__ inline int cst_off_xinv(int J) { return 3 * J + 2 + PMAX * PMAX; }
+__host__ __device__ inline int cst_size(int J) { return 3 * J + 2 + 2 * PMAX * PMAX; }
 
 // statistics layout of one slab row: NSTAT item statistics x J, then NG globals
 template <int MODEL, int PHASE> struct Stats;
@@ -294,7 +296,33 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             if (MODEL == CROSSQR && PHASE == 1) gacc[0 * R + r] += (double)ze * (double)ze;
         }
 
-        // ---------------- cell phase: log-likelihood, next-sweep omega / nu, item statistics
+        // ---------------- cell phase A (PHASE 0): omega_{t+1} | theta_t, a_t, b_t  (src/Draw.pl.jl:36-40)
+        // Persistent lanes: every lane walks through its own IPL cells, one single-block PG attempt per trip, and moves on
+        // to its next cell as soon as a draw is accepted, so a wave pays max-over-lanes of the TOTAL attempts rather than the
+        // sum over cells of the max.  Attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
+        if constexpr (PHASE == 0) {
+            int j = s;
+            bool active = rowok && j < J;
+            uint32_t att = 0;
+            real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
+            const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
+            while (__any(active)) {
+                if (active) {
+                    uint32_t w0, w1, w2, w3;
+                    philox4x32_10((uint32_t)i, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                    real w;
+                    const bool acc = pg1_attempt<real>(z, w0, w1, w2, w3, w);
+                    if (acc || att + 1u >= (uint32_t)MAX_TRIES) {
+                        A.omega[base + j] = w;
+                        j += W; att = 0;
+                        active = j < J;
+                        if (active) z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j]));
+                    } else ++att;
+                }
+            }
+        }
+
+        // ---------------- cell phase B: log-likelihood, next-sweep nu (CrossQr pass B), item statistics (lockstep over k)
         for (int k = 0; k < IPL; ++k) {
             const int j = s + W * k;
             const bool ok = rowok && j < J;
@@ -316,10 +344,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                             ll += -0.5 * LOG_2PI - 0.5 * (double)(sh_lsig[j] + e * e * sh_isig[j]);
                         }
                     }
-                    // omega_{t+1} | theta_t, a_t, b_t : src/Draw.pl.jl:36-40
-                    Stream st(A.seed, A.chain, SITE_OMEGA, (uint32_t)i, (uint32_t)j, sweep + 1u);
-                    const real w = pg1<real>(st, eta);
-                    A.omega[base + j] = w;
+                    const real w = A.omega[base + j];      // written by this lane in phase A
                     v[0] = w; v[1] = w * th; v[2] = w * th * th; v[3] = kap * th;
                     if constexpr (MODEL == RTIRT || MODEL == LATENTQR) v[4] = c * ze;
                     if constexpr (MODEL == CROSSQR) {
@@ -397,39 +422,6 @@ struct TinyArgs {
     int nq;               // number of small qr entries recorded per sweep
 };
 
-// dense helpers on tiny matrices (column-major, n <= 2*PMAX), executed by one thread
-__device__ inline void d_inverse(int n, const double* Ain, double* Ainv, double* work /* n*2n */)
-{
-    const int n2 = 2 * n;
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { work[i * n2 + j] = Ain[i + j * n]; work[i * n2 + n + j] = (i == j) ? 1.0 : 0.0; }
-    for (int c = 0; c < n; ++c) {
-        int piv = c; double best = fabs(work[c * n2 + c]);
-        for (int rr = c + 1; rr < n; ++rr) { const double v = fabs(work[rr * n2 + c]); if (v > best) { best = v; piv = rr; } }
-        if (piv != c) for (int j = 0; j < n2; ++j) { const double t = work[c * n2 + j]; work[c * n2 + j] = work[piv * n2 + j]; work[piv * n2 + j] = t; }
-        const double d = 1.0 / work[c * n2 + c];
-        for (int j = 0; j < n2; ++j) work[c * n2 + j] *= d;
-        for (int rr = 0; rr < n; ++rr) if (rr != c) {
-            const double f = work[rr * n2 + c];
-            if (f != 0.0) for (int j = 0; j < n2; ++j) work[rr * n2 + j] -= f * work[c * n2 + j];
-        }
-    }
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Ainv[i + j * n] = work[i * n2 + n + j];
-}
-__device__ inline void d_chol(int n, const double* A, double* L)
-{
-    for (int e = 0; e < n * n; ++e) L[e] = 0.0;
-    for (int j = 0; j < n; ++j) {
-        double d = A[j + j * n];
-        for (int k = 0; k < j; ++k) d -= L[j + k * n] * L[j + k * n];
-        d = sqrt(d);
-        L[j + j * n] = d;
-        for (int i = j + 1; i < n; ++i) {
-            double v = A[i + j * n];
-            for (int k = 0; k < j; ++k) v -= L[i + k * n] * L[j + k * n];
-            L[i + j * n] = v / d;
-        }
-    }
-}
 __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
 {
     const double d1 = 1.0 / sqrt(S[0]);
@@ -439,8 +431,17 @@ __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
     S[0] = 1.0; S[3] = 1.0;
 }
 
+// Lanes of ONE wave exchange data through LDS: DS instructions of a wave execute in order, so a compiler-level fence is all
+// that is needed between a phase that writes and a phase that reads.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int TINY_THREADS = 1024;
-constexpr int TINY_WORK = 2 * PMAX * 4 * PMAX + 3 * (2 * PMAX) * (2 * PMAX) + 8 * PMAX;   // scratch doubles for the structural thread
+constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX;   // LDS scratch doubles for the structural wave
 
 // STEP: 0 = the per-sweep step of single-pass models / CrossQr step 1; 1 = CrossQr step 2 (lambda, sig2t)
 template <int MODEL, int STEP>
@@ -462,28 +463,25 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     double* work = part + 4 * (NS0 > NS1 ? NS0 : NS1);      // TINY_WORK scratch
     const int tid = threadIdx.x;
 
-    // ---- fixed-order slab reduction: 4 partial chains per statistic, then their sum
-    {
+    // ---- fixed-order slab reduction: 4 chains per statistic, each with 8 independent partial sums (loads in flight)
+    auto reduce = [&](const double* slab, int nb, int NS, double* out) {
         const int part_id = tid >> 8, e0 = tid & 255;
-        for (int e = e0; e < NS0; e += 256) {
-            double t = 0.0;
-            for (int b = part_id; b < T.nb0; b += 4) t += T.slab0[(size_t)b * NS0 + e];
-            part[part_id * NS0 + e] = t;
-        }
-        __syncthreads();
-        for (int e = tid; e < NS0; e += TINY_THREADS) st0[e] = (part[e] + part[NS0 + e]) + (part[2 * NS0 + e] + part[3 * NS0 + e]);
-        __syncthreads();
-        if (MODEL == CROSSQR) {
-            for (int e = e0; e < NS1; e += 256) {
-                double t = 0.0;
-                for (int b = part_id; b < T.nb1; b += 4) t += T.slab1[(size_t)b * NS1 + e];
-                part[part_id * NS1 + e] = t;
+        for (int e = e0; e < NS; e += 256) {
+            double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int b = part_id;
+            for (; b + 28 < nb; b += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] += slab[(size_t)(b + 4 * u) * NS + e];
             }
-            __syncthreads();
-            for (int e = tid; e < NS1; e += TINY_THREADS) st1[e] = (part[e] + part[NS1 + e]) + (part[2 * NS1 + e] + part[3 * NS1 + e]);
-            __syncthreads();
+            for (; b < nb; b += 4) t[0] += slab[(size_t)b * NS + e];
+            part[part_id * NS + e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         }
-    }
+        __syncthreads();
+        for (int e = tid; e < NS; e += TINY_THREADS) out[e] = (part[e] + part[NS + e]) + (part[2 * NS + e] + part[3 * NS + e]);
+        __syncthreads();
+    };
+    reduce(T.slab0, T.nb0, NS0, st0);
+    if (MODEL == CROSSQR && STEP == 0) reduce(T.slab1, T.nb1, NS1, st1);
 
     const uint32_t prev_row = T.ctl->row;
     const uint32_t sweep = T.ctl->sweep + ((T.mode == 0 && STEP == 0) ? 1u : 0u);   // the sweep being drawn
@@ -502,108 +500,151 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     const double* csq = T.cst + cst_off_csq(J);
     const double muLam = T.cst[cst_off_mu(J)], sdLam = T.cst[cst_off_mu(J) + 1];
     const double* XtX = T.cst + cst_off_xtx(J);             // p x p, column-major with leading dimension PMAX
+    const double* Xinv = T.cst + cst_off_xinv(J);           // (x'x)^-1, same layout
     double* par = T.par;
     double* Sigp = par + par_off_sigp(J);
     double* beta = par + par_off_beta(J);
+    const double* G0 = st0 + NSTAT0 * J;                    // global statistics of slab0
 
-    // Item statistics S0..: st0[q*J + j]; globals after NSTAT0*J
-    const double* G0 = st0 + NSTAT0 * J;
-
-    // =========================================================== structural draws: thread 0 (wave 0)
-    if (tid == 0 && STEP == 0) {
+    // =========================================================== structural draws: wave 0
+    if (tid < 64 && STEP == 0) {
+        const int lane = tid;
         if (MODEL == MLIRT) {
             // getSubjCoefficientsMlIrt src/Draw.pl.jl:351-357 : beta = (x'x) \ x'theta ; beta[1] = 0 unless intercept
-            double* A = work, *Ai = work + PMAX * PMAX, *w2 = Ai + PMAX * PMAX;
-            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) A[u + v * p] = XtX[u + v * PMAX];
-            d_inverse(p, A, Ai, w2);
-            for (int u = 0; u < p; ++u) { double t = 0.0; for (int v = 0; v < p; ++v) t += Ai[u + v * p] * G0[v]; beta[u] = t; }
-            if (!T.intercept) beta[0] = 0.0;
+            if (lane < p) {
+                double t = 0.0;
+                for (int v = 0; v < p; ++v) t += Xinv[lane + v * PMAX] * G0[v];
+                beta[lane] = (lane == 0 && !T.intercept) ? 0.0 : t;
+            }
         } else if (MODEL == RTIRT) {
-            // drawSubjCoefficients src/Draw.pl.jl:380-393 (precision = 1 .+ kron(inv(Sigp), x'x): +1 on EVERY element)
+            // drawSubjCoefficients src/Draw.pl.jl:380-393.  Posterior precision = 11' + kron(inv(Sigp), x'x) (the reference's
+            // `1/sigma^2 .+ M` adds 1 to EVERY element), so by Sherman-Morrison
+            //   parV = Minv - v v'/(1 + 1'v),  Minv = kron(Sigp, (x'x)^-1),  v = Minv 1.
             const int n = 2 * p;
-            double* P = work, *V = P + n * n, *L = V + n * n, *w2 = L + n * n;   // w2: n*2n
-            double* tv = w2 + 2 * n * n, *pm = tv + n, *z = pm + n;
+            double* V = work, *L = V + n * n, *tv = L + n * n, *pm = tv + n, *zv = pm + n, *vv = zv + n, *bn = vv + n, *rs = bn + n;
             const double* xt = G0, *xz = G0 + p;
             const double tt = G0[2 * p], tz = G0[2 * p + 1], zz = G0[2 * p + 2];
-            double iO[4];
-            { const double det = Sigp[0] * Sigp[3] - Sigp[1] * Sigp[2]; iO[0] = Sigp[3] / det; iO[1] = -Sigp[1] / det; iO[2] = -Sigp[2] / det; iO[3] = Sigp[0] / det; }
-            for (int i1 = 0; i1 < 2; ++i1) for (int j1 = 0; j1 < 2; ++j1)
-                for (int i2 = 0; i2 < p; ++i2) for (int j2 = 0; j2 < p; ++j2)
-                    P[(i1 * p + i2) + (j1 * p + j2) * n] = 1.0 + iO[i1 + j1 * 2] * XtX[i2 + j2 * PMAX];
-            d_inverse(n, P, V, w2);
-            for (int cc = 0; cc < 2; ++cc) for (int rr = 0; rr < p; ++rr) tv[cc * p + rr] = 0.0 + xt[rr] * iO[cc] + xz[rr] * iO[cc + 2];
-            for (int i = 0; i < n; ++i) { double t = 0.0; for (int j = 0; j < n; ++j) t += V[i + j * n] * tv[j]; pm[i] = t; }
-            for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) V[i + j * n] = V[j + i * n];   // Symmetric(parV): upper triangle
-            d_chol(n, V, L);
-            Stream sb(T.seed, T.chain, SITE_BETA, 0u, 0u, sweep);
-            for (int i = 0; i < n; ++i) z[i] = normal<double>(sb);
-            double bnew[2 * PMAX];
-            for (int i = 0; i < n; ++i) { double t = pm[i]; for (int j = 0; j <= i; ++j) t += L[i + j * n] * z[j]; bnew[i] = t; }
-            if (!T.intercept) { bnew[0] = 0.0; bnew[p] = 0.0; }
-            for (int u = 0; u < p; ++u) { beta[u] = bnew[u]; beta[PMAX + u] = bnew[p + u]; }
-            // drawSubjCovariance src/Draw.pl.jl:499-515 : InverseWishart(N+3, e'e + I)
-            double bAb[4] = {0, 0, 0, 0}, bx[4];
-            for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) {
-                double t = 0.0;
-                for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) t += bnew[a_ * p + u] * XtX[u + v * PMAX] * bnew[b_ * p + v];
-                bAb[a_ + 2 * b_] = t;
+            const double s00 = Sigp[0], s10 = Sigp[1], s01 = Sigp[2], s11 = Sigp[3];
+            const double sdet = s00 * s11 - s10 * s01;
+            const double iO[4] = { s11 / sdet, -s10 / sdet, -s01 / sdet, s00 / sdet };
+            if (lane < p) { double t = 0.0; for (int w = 0; w < p; ++w) t += Xinv[lane + w * PMAX]; rs[lane] = t; }
+            wave_sync();
+            if (lane < n) {
+                const int a_ = lane / p, u = lane % p;
+                vv[lane] = (Sigp[a_] + Sigp[a_ + 2]) * rs[u];
+                tv[lane] = 0.0 + xt[u] * iO[a_] + xz[u] * iO[a_ + 2];      // vec(x'eta * inv(Sigp)')
             }
-            // bx[a,b] = beta_a' x'eta_b
-            for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) {
-                double t = 0.0; const double* xe = b_ == 0 ? xt : xz;
-                for (int u = 0; u < p; ++u) t += bnew[a_ * p + u] * xe[u];
-                bx[a_ + 2 * b_] = t;
+            wave_sync();
+            double cden = 1.0;
+            for (int i = 0; i < n; ++i) cden += vv[i];
+            for (int e = lane; e < n * n; e += 64) {
+                int i = e % n, jj = e / n;
+                if (i > jj) { const int t_ = i; i = jj; jj = t_; }              // Symmetric(parV): upper triangle
+                const int a_ = i / p, u = i % p, b_ = jj / p, w = jj % p;
+                V[e] = Sigp[a_ + 2 * b_] * Xinv[u + w * PMAX] - vv[i] * vv[jj] / cden;
             }
-            const double ee00 = tt - 2.0 * bx[0] + bAb[0];
-            const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
-            const double ee11 = zz - 2.0 * bx[3] + bAb[3];
-            const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
-            double Pi[4]; { const double det = Psi[0] * Psi[3] - Psi[1] * Psi[2]; Pi[0] = Psi[3] / det; Pi[1] = -Psi[1] / det; Pi[2] = -Psi[2] / det; Pi[3] = Psi[0] / det; }
-            const double l00 = sqrt(Pi[0]), l10 = Pi[1] / l00, l11 = sqrt(Pi[3] - l10 * l10);
-            const double df = Nd + 3.0;
-            Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
-            const double c1 = sqrt(chisq(ss, df));
-            const double n21 = normal<double>(ss);
-            const double c2 = sqrt(chisq(ss, df - 1.0));
-            const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
-            const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
-            const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
-            double S[4] = { Wm[3] / det, -Wm[1] / det, -Wm[2] / det, Wm[0] / det };
-            if (T.cov2one) d_cov2one(S);
-            for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+            wave_sync();
+            if (lane < n) { double t = 0.0; for (int jj = 0; jj < n; ++jj) t += V[lane + jj * n] * tv[jj]; pm[lane] = t; }
+            if (lane == 0) {
+                // Cholesky (lower) of parV and the 2p standard normals, in stream order
+                for (int jj = 0; jj < n; ++jj) {
+                    double d = V[jj + jj * n];
+                    for (int k = 0; k < jj; ++k) d -= L[jj + k * n] * L[jj + k * n];
+                    d = sqrt(d);
+                    L[jj + jj * n] = d;
+                    for (int i = jj + 1; i < n; ++i) {
+                        double v = V[i + jj * n];
+                        for (int k = 0; k < jj; ++k) v -= L[i + k * n] * L[jj + k * n];
+                        L[i + jj * n] = v / d;
+                    }
+                }
+                Stream sb(T.seed, T.chain, SITE_BETA, 0u, 0u, sweep);
+                for (int i = 0; i < n; ++i) zv[i] = normal<double>(sb);
+            }
+            wave_sync();
+            if (lane < n) {
+                double t = pm[lane];
+                for (int jj = 0; jj <= lane; ++jj) t += L[lane + jj * n] * zv[jj];
+                if (!T.intercept && (lane == 0 || lane == p)) t = 0.0;          // src/GibbsRtIrt.pl.jl:293-295
+                bn[lane] = t;
+                beta[(lane / p) * PMAX + (lane % p)] = t;
+            }
+            wave_sync();
+            if (lane == 0) {
+                // drawSubjCovariance src/Draw.pl.jl:499-515 : InverseWishart(N+3, e'e + I), e'e from sufficient statistics
+                double bAb[4] = {0, 0, 0, 0}, bx[4];
+                for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) {
+                    double t = 0.0;
+                    for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) t += bn[a_ * p + u] * XtX[u + v * PMAX] * bn[b_ * p + v];
+                    bAb[a_ + 2 * b_] = t;
+                    double t2 = 0.0; const double* xe = b_ == 0 ? xt : xz;
+                    for (int u = 0; u < p; ++u) t2 += bn[a_ * p + u] * xe[u];
+                    bx[a_ + 2 * b_] = t2;
+                }
+                const double ee00 = tt - 2.0 * bx[0] + bAb[0];
+                const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
+                const double ee11 = zz - 2.0 * bx[3] + bAb[3];
+                const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
+                const double pdet = Psi[0] * Psi[3] - Psi[1] * Psi[2];
+                const double Pi[4] = { Psi[3] / pdet, -Psi[1] / pdet, -Psi[2] / pdet, Psi[0] / pdet };
+                const double l00 = sqrt(Pi[0]), l10 = Pi[1] / l00, l11 = sqrt(Pi[3] - l10 * l10);
+                const double df = Nd + 3.0;
+                Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
+                const double c1 = sqrt(chisq(ss, df));
+                const double n21 = normal<double>(ss);
+                const double c2 = sqrt(chisq(ss, df - 1.0));
+                const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
+                const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
+                const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
+                double S[4] = { Wm[3] / det, -Wm[1] / det, -Wm[2] / det, Wm[0] / det };
+                if (T.cov2one) d_cov2one(S);
+                for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+            }
         } else if (MODEL == LATENTQR) {
-            // getSubjCoefficientsLatentQr src/Draw.pl.jl:446-458 : beta = (x'x)^-1 x'(zeta - k1 nu), x = [1 X theta]
-            const int q = p + 1;
-            const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
-            const double tu = G0[2 * p + 1], uu = G0[2 * p + 2], snu = G0[2 * p + 3], snu2 = G0[2 * p + 4];
-            double* A = work, *Ai = A + PMAX * PMAX, *w2 = Ai + PMAX * PMAX, *rhs = w2 + 2 * PMAX * PMAX;
-            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) A[u + v * q] = XtX[u + v * PMAX];
-            for (int u = 0; u < p; ++u) { A[u + p * q] = xt[u]; A[p + u * q] = xt[u]; rhs[u] = xu[u]; }
-            A[p + p * q] = tt; rhs[p] = tu;
-            d_inverse(q, A, Ai, w2);
-            double bnew[PMAX];
-            for (int u = 0; u < q; ++u) { double t = 0.0; for (int v = 0; v < q; ++v) t += Ai[u + v * q] * rhs[v]; bnew[u] = t; }
-            if (!T.intercept) bnew[0] = 0.0;
-            for (int u = 0; u < q; ++u) beta[u] = bnew[u];
-            // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
-            double sr2 = uu;
-            for (int u = 0; u < q; ++u) sr2 -= 2.0 * bnew[u] * rhs[u];
-            for (int u = 0; u < q; ++u) for (int v = 0; v < q; ++v) sr2 += bnew[u] * A[u + v * q] * bnew[v];
-            const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
-            const double parB = 1e-3 + sr2 * sw / sw2 + snu;
-            Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
-            const double v = invgamma(ss, 1e-3 + Nd * 3.0 / 2.0, parB);
-            double S[4] = { 1.0, 0.0, 0.0, v };
-            if (T.cov2one) d_cov2one(S);
-            for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+            // getSubjCoefficientsLatentQr src/Draw.pl.jl:446-458 : beta = (x'x)^-1 x'(zeta - k1 nu), x = [1 X theta];
+            // block inverse with the constant (X~'X~)^-1 and the Schur complement of the theta column.
+            if (lane == 0) {
+                const int q = p + 1;
+                const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
+                const double tu = G0[2 * p + 1], uu = G0[2 * p + 2], snu = G0[2 * p + 3], snu2 = G0[2 * p + 4];
+                double* h = work, *g = h + PMAX, *bn = g + PMAX;
+                double hx = 0.0, hu = 0.0;
+                for (int u = 0; u < p; ++u) {
+                    double t1 = 0.0, t2 = 0.0;
+                    for (int v = 0; v < p; ++v) { t1 += Xinv[u + v * PMAX] * xt[v]; t2 += Xinv[u + v * PMAX] * xu[v]; }
+                    h[u] = t1; g[u] = t2;
+                }
+                for (int u = 0; u < p; ++u) { hx += xt[u] * h[u]; hu += h[u] * xu[u]; }
+                const double b2 = (tu - hu) / (tt - hx);
+                for (int u = 0; u < p; ++u) bn[u] = g[u] - h[u] * b2;
+                bn[p] = b2;
+                if (!T.intercept) bn[0] = 0.0;                                   // src/GibbsRtIrtLatent.pl.jl:288-290
+                for (int u = 0; u < q; ++u) beta[u] = bn[u];
+                // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
+                double sr2 = uu;
+                for (int u = 0; u < p; ++u) sr2 -= 2.0 * bn[u] * xu[u];
+                sr2 -= 2.0 * bn[p] * tu;
+                for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
+                for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
+                sr2 += bn[p] * bn[p] * tt;
+                const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
+                const double parB = 1e-3 + sr2 * sw / sw2 + snu;
+                Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
+                const double v = invgamma(ss, 1e-3 + Nd * 3.0 / 2.0, parB);
+                double S[4] = { 1.0, 0.0, 0.0, v };
+                if (T.cov2one) d_cov2one(S);
+                for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+            }
         } else if (MODEL == CROSSQR) {
-            // drawSubjCovarianceCross src/Draw.pl.jl:542-557
-            const double zz = st1[NSTAT1 * J + 0];
-            Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
-            const double v = invgamma(ss, 1e-3 + Nd / 2.0, 1e-3 + zz / 2.0);
-            double S[4] = { 1.0, 0.0, 0.0, v };
-            if (T.cov2one) d_cov2one(S);
-            for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+            if (lane == 0) {
+                // drawSubjCovarianceCross src/Draw.pl.jl:542-557
+                const double zz = st1[NSTAT1 * J + 0];
+                Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
+                const double v = invgamma(ss, 1e-3 + Nd / 2.0, 1e-3 + zz / 2.0);
+                double S[4] = { 1.0, 0.0, 0.0, v };
+                if (T.cov2one) d_cov2one(S);
+                for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+            }
         }
     }
 
@@ -715,8 +756,9 @@ __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uin
     case 4: v = (double)invgauss<real>(st, (real)par0[k], (real)par1[k]); break;
     case 5: v = truncnorm0(st, par0[k], par1[k]); break;
     case 6: v = gamma_mt(st, par0[k]); break;
-    case 7: v = (double)pg_mass_texpon<real>((real)par0[k]); break;
+    case 7: { const real z = (real)par0[k]; v = (double)pg_tail_weight<real>(z, real(0.125) * Const<real>::PI * Const<real>::PI + real(0.5) * z * z); } break;
     case 8: v = (double)qr_weight<real>(st, (real)par0[k], (real)par1[k]); break;
+    case 9: v = (double)ndtri((real)par0[k]); break;
     }
     out[k] = v;
 }

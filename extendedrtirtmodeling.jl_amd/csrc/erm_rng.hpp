@@ -7,8 +7,8 @@
 //   uniform: fp64 (x + 1/2) 2^-32; fp32 ((x >> 9) + 1/2) 2^-23 (the same value truncated to 23 bits: every value is exactly
 //            representable in fp32, lies strictly inside (0,1) and never makes cospi(2u) vanish)
 //   expo   : -log(u);  normal: sqrt(-2 log u1) cos(2 pi u2) (two words per variate)
-//   PG(1,c): Polson-Scott-Windle / Devroye alternating-series sampler, t = 0.64
-//            (replaces PolyaGammaPSWSampler(1, eta) at /root/reference/src/Draw.pl.jl:38)
+//   PG(1,c): Polson-Scott-Windle / Devroye alternating-series sampler, t = 0.64, as a single-level rejection sampler
+//            with one Philox block per attempt (replaces PolyaGammaPSWSampler(1, eta) at /root/reference/src/Draw.pl.jl:38)
 //   IG     : Michael-Schucany-Haas (replaces Distributions.InverseGaussian at src/Draw.pl.jl:312,335)
 //   TN, Gamma (fp64 only; item-level draws): Robert (1995) / Marsaglia-Tsang (2000)
 #pragma once
@@ -108,13 +108,6 @@ template <typename real> __device__ __forceinline__ real normal(Stream& s)
     return r_sqrt(real(-2) * r_log(u1)) * r_cospi(real(2) * u2);
 }
 
-// log Phi(x), stable in both tails
-template <typename real> __device__ __forceinline__ real log_pnorm(real x)
-{
-    if (x > real(0)) return r_log1p(real(-0.5) * r_erfc(x * Const<real>::SQRT1_2));
-    return r_log(real(0.5) * r_erfc(-x * Const<real>::SQRT1_2));
-}
-
 // IG(mu, lambda), Michael-Schucany-Haas with the cancellation-free smaller root
 template <typename real> __device__ __forceinline__ real invgauss(Stream& s, real mu, real lambda)
 {
@@ -138,77 +131,125 @@ template <typename real> __device__ __forceinline__ real qr_weight(Stream& s, re
     return nu;
 }
 
-// ---- Polya-Gamma PG(1, c) -------------------------------------------------------------------
-template <typename real> __device__ __forceinline__ real pg_an(int n, real x)
+// ---- standard normal quantile -----------------------------------------------------------------
+// fp32: Giles' (2010) single-precision erfinv polynomial (relative error ~1.3e-7), argument formed from p without cancellation.
+__device__ __forceinline__ float giles_erfinv_poly(float w)
 {
-    const real t = real(0.64);
-    const real kk = (real(n) + real(0.5)) * Const<real>::PI;
-    if (x > t) return kk * r_exp(real(-0.5) * kk * kk * x);
-    const real h = real(2) / (Const<real>::PI * x);
-    const real nh = real(n) + real(0.5);
-    return kk * h * r_sqrt(h) * r_exp(real(-2) * nh * nh / x);
+    float pl;
+    if (w < 5.0f) {
+        w -= 2.5f;
+        pl = 2.81022636e-08f; pl = fmaf(pl, w, 3.43273939e-07f); pl = fmaf(pl, w, -3.5233877e-06f); pl = fmaf(pl, w, -4.39150654e-06f);
+        pl = fmaf(pl, w, 0.00021858087f); pl = fmaf(pl, w, -0.00125372503f); pl = fmaf(pl, w, -0.00417768164f); pl = fmaf(pl, w, 0.246640727f);
+        pl = fmaf(pl, w, 1.50140941f);
+    } else {
+        w = __fsqrt_rn(w) - 3.0f;
+        pl = -0.000200214257f; pl = fmaf(pl, w, 0.000100950558f); pl = fmaf(pl, w, 0.00134934322f); pl = fmaf(pl, w, -0.00367342844f);
+        pl = fmaf(pl, w, 0.00573950773f); pl = fmaf(pl, w, -0.0076224613f); pl = fmaf(pl, w, 0.00943887047f); pl = fmaf(pl, w, 1.00167406f);
+        pl = fmaf(pl, w, 2.83297682f);
+    }
+    return pl;
+}
+__device__ __forceinline__ float ndtri(float p)
+{
+    const float x = 2.0f * p - 1.0f;
+    const float w = -__logf(4.0f * p * (1.0f - p));
+    return 1.41421356237f * giles_erfinv_poly(w) * x;
+}
+// fp64: the same polynomial as a starting point, polished by three Newton steps on Phi(x) = q in the lower tail
+__device__ __forceinline__ double ndtri(double p)
+{
+    const bool upper = p > 0.5;
+    const double q = upper ? 1.0 - p : p;
+    const double xx = 2.0 * q - 1.0;
+    double w = -log(4.0 * q * (1.0 - q)), pl;
+    if (w < 5.0) {
+        w -= 2.5;
+        pl = 2.81022636e-08; pl = 3.43273939e-07 + pl * w; pl = -3.5233877e-06 + pl * w; pl = -4.39150654e-06 + pl * w;
+        pl = 0.00021858087 + pl * w; pl = -0.00125372503 + pl * w; pl = -0.00417768164 + pl * w; pl = 0.246640727 + pl * w;
+        pl = 1.50140941 + pl * w;
+    } else {
+        w = sqrt(w) - 3.0;
+        pl = -0.000200214257; pl = 0.000100950558 + pl * w; pl = 0.00134934322 + pl * w; pl = -0.00367342844 + pl * w;
+        pl = 0.00573950773 + pl * w; pl = -0.0076224613 + pl * w; pl = 0.00943887047 + pl * w; pl = 1.00167406 + pl * w;
+        pl = 2.83297682 + pl * w;
+    }
+    double x = 1.41421356237309504880 * pl * xx;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double cdf = 0.5 * erfc(-x * 0.70710678118654752440);
+        const double pdf = 0.3989422804014327 * exp(-0.5 * x * x);
+        x -= (cdf - q) / pdf;
+    }
+    return upper ? -x : x;
 }
 
-template <typename real> __device__ __forceinline__ real pg_mass_texpon(real z)
+template <typename real> __device__ __forceinline__ real word_to_unif(uint32_t w);
+template <> __device__ __forceinline__ double word_to_unif<double>(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
+template <> __device__ __forceinline__ float word_to_unif<float>(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+
+// ---- Polya-Gamma PG(1, c) -------------------------------------------------------------------
+// Single-level rejection sampler for J*(1, z): one attempt = one Philox block (u0..u3), no inner loop.  Envelope pieces:
+//   x > t           : (pi/2) e^{-K x}, K = pi^2/8 + z^2/2, mass p = pi/(2K) e^{-K t}
+//   x <= t, z < 1/t : the Levy kernel a_0(x), mass q0 = 4 Phi(-1/sqrt t); acceptance factor e^{-z^2 x/2}
+//   x <= t, z >= 1/t: the IG(1/z,1) kernel on all x > 0, mass 2 e^{-z}; draws with x > t rejected
+// followed by the alternating-series test in ratio form (rho_n = a_n/a_0).  Specification shared with oracle/orc_rng.h.
+template <typename real> __device__ __forceinline__ real pg_tail_weight(real z, real K)
+{
+    const real t = real(0.64);
+    const real p = Const<real>::PI / (real(2) * K) * r_exp(-K * t);
+    const real qenv = (z < real(1) / t) ? real(0.42259909466742100) : real(2) * r_exp(-z);
+    return p / (p + qenv);
+}
+
+template <typename real>
+__device__ __forceinline__ bool pg1_attempt(real z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, real& out)
 {
     const real t = real(0.64);
     const real PI = Const<real>::PI;
-    const real fz = real(0.125) * PI * PI + real(0.5) * z * z;
-    const real rt = r_sqrt(real(1) / t);
-    const real b = rt * (t * z - real(1));
-    const real a = -rt * (t * z + real(1));
-    const real x0 = r_log(fz) + fz * t;
-    const real xb = x0 - z + log_pnorm<real>(b);
-    const real xa = x0 + z + log_pnorm<real>(a);
-    const real qdivp = real(4) / PI * (r_exp(xb) + r_exp(xa));
-    return real(1) / (real(1) + qdivp);
-}
-
-template <typename real> __device__ __forceinline__ real pg_rtigauss(Stream& s, real z)
-{
-    const real t = real(0.64);
+    const real K = real(0.125) * PI * PI + real(0.5) * z * z;
+    const real r = pg_tail_weight<real>(z, K);
+    const real u0 = word_to_unif<real>(w0), u1 = word_to_unif<real>(w1), u2 = word_to_unif<real>(w2), V = word_to_unif<real>(w3);
     real x;
-    if (z < real(1) / t) {
-        // every rejection loop is bounded (MAX_TRIES) so that a non-finite input can never hang a wave
-        real alpha;
-        int tries = 0;
-        do {
-            real e1, e2;
-            do { e1 = expo<real>(s); e2 = expo<real>(s); } while (e1 * e1 > real(2) * e2 / t && ++tries < MAX_TRIES);
-            x = real(1) + e1 * t;
-            x = t / (x * x);
-            alpha = r_exp(real(-0.5) * z * z * x);
-        } while (uniform<real>(s) > alpha && ++tries < MAX_TRIES);
+    bool ok = true;
+    if (u0 < r) {
+        x = t - r_log(u1) / K;
+    } else if (z < real(1) / t) {
+        const real zt = ndtri(u1 * real(0.10564977366685525));       // <= -1/sqrt(t)
+        x = real(1) / (zt * zt);
+        ok = !(u2 > r_exp(real(-0.5) * z * z * x));
     } else {
-        const real mu = real(1) / z;
-        int tries = 0;
-        do { x = invgauss<real>(s, mu, real(1)); } while (x > t && ++tries < MAX_TRIES);
+        const real mu = real(1) / z, nrm = ndtri(u1);
+        const real ww = mu * nrm * nrm;
+        const real sq = r_sqrt(ww) * r_sqrt(real(4) + ww), den = sq + ww;
+        const real q = den > real(0) ? real(2) * r_sqrt(ww) / den : real(1);
+        const real x1 = mu * q * q;
+        x = (u2 >= mu / (mu + x1)) ? mu * mu / x1 : x1;
+        ok = !(x > t);
     }
-    return x;
+    out = real(0.25) * x;
+    if (!ok) return false;
+    // alternating series: accept at odd n if V <= S_n, reject at even n if V > S_n
+    const real e1 = (x > t) ? real(-0.5) * PI * PI * x : real(-2) / x;     // rho_n = (2n+1) exp(n(n+1) e1)
+    real S = real(1) - real(3) * r_exp(real(2) * e1);
+    if (V <= S) return true;
+    for (int n = 2; n <= 200; ++n) {
+        const real rho = real(2 * n + 1) * r_exp(real(n * (n + 1)) * e1);
+        if (n & 1) { S -= rho; if (V <= S) return true; }
+        else       { S += rho; if (V > S) return false; }
+    }
+    return true;
 }
 
+// draw addressed by a stream: attempt k consumes block k
 template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c)
 {
-    const real t = real(0.64);
-    const real PI = Const<real>::PI;
     const real z = real(0.5) * r_abs(c);
-    const real fz = real(0.125) * PI * PI + real(0.5) * z * z;
-    const real r = pg_mass_texpon<real>(z);
-    for (int tries = 0;; ++tries) {
-        real x;
-        if (uniform<real>(s) < r) x = t + expo<real>(s) / fz;
-        else x = pg_rtigauss<real>(s, z);
-        real S = pg_an<real>(0, x);
-        const real y = uniform<real>(s) * S;
-        int n = 0;
-        for (;;) {
-            ++n;
-            if (n & 1) { S -= pg_an<real>(n, x); if (y <= S) return real(0.25) * x; }
-            else       { S += pg_an<real>(n, x); if (y > S) break; }
-            if (n > 200) return real(0.25) * x;
-        }
-        if (tries >= MAX_TRIES) return real(0.25) * x;
+    real out = real(0);
+    for (int tries = 0; tries < MAX_TRIES; ++tries) {
+        const uint32_t w0 = s.next(), w1 = s.next(), w2 = s.next(), w3 = s.next();
+        if (pg1_attempt<real>(z, w0, w1, w2, w3, out)) break;
     }
+    return out;
 }
 
 // ---- item-level samplers (fp64 only) --------------------------------------------------------

@@ -427,6 +427,23 @@ template <typename real> struct Engine : EngineBase {
                 }
                 cst[cst_off_xtx(J) + u + v * PMAX] = t;
             }
+            {   // (x'x)^-1 by Gauss-Jordan with partial pivoting (fp64, p <= PMAX)
+                std::vector<double> M((size_t)pp * 2 * pp, 0.0);
+                for (int i = 0; i < pp; ++i) { for (int jx = 0; jx < pp; ++jx) M[(size_t)i * 2 * pp + jx] = cst[cst_off_xtx(J) + i + jx * PMAX]; M[(size_t)i * 2 * pp + pp + i] = 1.0; }
+                for (int c = 0; c < pp; ++c) {
+                    int piv = c;
+                    for (int r = c + 1; r < pp; ++r) if (std::fabs(M[(size_t)r * 2 * pp + c]) > std::fabs(M[(size_t)piv * 2 * pp + c])) piv = r;
+                    if (!(std::fabs(M[(size_t)piv * 2 * pp + c]) > 0.0)) return fail(ERM_ERR_ARG, "x'x is singular (collinear covariates)");
+                    if (piv != c) for (int jx = 0; jx < 2 * pp; ++jx) std::swap(M[(size_t)c * 2 * pp + jx], M[(size_t)piv * 2 * pp + jx]);
+                    const double d = M[(size_t)c * 2 * pp + c];
+                    for (int jx = 0; jx < 2 * pp; ++jx) M[(size_t)c * 2 * pp + jx] /= d;
+                    for (int r = 0; r < pp; ++r) if (r != c) {
+                        const double f = M[(size_t)r * 2 * pp + c];
+                        if (f != 0.0) for (int jx = 0; jx < 2 * pp; ++jx) M[(size_t)r * 2 * pp + jx] -= f * M[(size_t)c * 2 * pp + jx];
+                    }
+                }
+                for (int i = 0; i < pp; ++i) for (int jx = 0; jx < pp; ++jx) cst[cst_off_xinv(J) + i + jx * PMAX] = M[(size_t)i * 2 * pp + pp + jx];
+            }
             if (Fk > 0) {
                 for (int f = 0; f < Fk; ++f) for (int64_t i = 0; i < N; ++i) xr[(size_t)i * Fk + f] = (real)X[(size_t)f * N + i];
                 HIPCHK(hipMemcpy(dX.p, xr.data(), (size_t)N * Fk * sizeof(real), hipMemcpyHostToDevice));

@@ -675,7 +675,7 @@ int orc_run(const orc_config* c, const orc_data* d, orc_state* s, int64_t sweep0
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32_10(ctr, key, out); }
 
 /* which: 0 u32->unif, 1 normal, 2 expo, 3 pg1(par0[k]), 4 invgauss(par0[k], par1[k]), 5 truncnorm0(par0,par1),
- * 6 gamma(par0), 7 mass_texpon(par0) (no rng), 8 qr_weight(parA=par0, parB=par1)
+ * 6 gamma(par0), 7 pg tail weight(par0) (no rng), 8 qr_weight(parA=par0, parB=par1), 9 ndtri(par0) (no rng)
  * element k uses stream (seed, chain 0, site, i = k, j = 0, sweep) */
 void orc_sample_batch(int which, uint64_t seed, int site, uint32_t sweep, int64_t n, const double* par0, const double* par1, double* out)
 {
@@ -689,8 +689,9 @@ void orc_sample_batch(int which, uint64_t seed, int site, uint32_t sweep, int64_
         case 4: out[k] = orc_invgauss(&st, par0[k], par1[k]); break;
         case 5: out[k] = orc_truncnorm0(&st, par0[k], par1[k]); break;
         case 6: out[k] = orc_gamma(&st, par0[k]); break;
-        case 7: out[k] = orc_pg_mass_texpon(par0[k]); break;
+        case 7: out[k] = orc_pg_tail_weight(par0[k]); break;
         case 8: out[k] = qr_weight(&st, par0[k], par1[k]); break;
+        case 9: out[k] = orc_ndtri(par0[k]); break;
         }
     }
 }

@@ -112,71 +112,107 @@ static inline double orc_invgauss(orc_stream* s, double mu, double lambda)
     return (u >= mu / (mu + x1)) ? mu * mu / x1 : x1;
 }
 
-/* ---- Polya-Gamma PG(1, c) ---- */
-#define ORC_PG_T 0.64
-
-static inline double orc_pg_an(int n, double x)
+/* ---- standard normal quantile: Giles' (2010) single-precision erfinv polynomial as a starting point,
+ * polished by three Newton steps on Phi(x) = p evaluated through erfc in the lower tail (accurate to ~1e-15). */
+static inline double orc_ndtri(double p)
 {
-    double kk = (n + 0.5) * ORC_PI;
-    if (x > ORC_PG_T) return kk * exp(-0.5 * kk * kk * x);
-    double h = 2.0 / (ORC_PI * x);
-    return kk * h * sqrt(h) * exp(-2.0 * (n + 0.5) * (n + 0.5) / x);
-}
-
-/* probability that the proposal comes from the exponential tail: p/(p+q) */
-static inline double orc_pg_mass_texpon(double z)
-{
-    const double t = ORC_PG_T;
-    double fz = 0.125 * ORC_PI * ORC_PI + 0.5 * z * z;
-    double b = sqrt(1.0 / t) * (t * z - 1.0);
-    double a = -sqrt(1.0 / t) * (t * z + 1.0);
-    double x0 = log(fz) + fz * t;
-    double xb = x0 - z + orc_log_pnorm(b);
-    double xa = x0 + z + orc_log_pnorm(a);
-    double qdivp = 4.0 / ORC_PI * (exp(xb) + exp(xa));
-    return 1.0 / (1.0 + qdivp);
-}
-
-/* IG(1/z, 1) truncated to (0, t) */
-static inline double orc_pg_rtigauss(orc_stream* s, double z)
-{
-    const double t = ORC_PG_T;
-    double x;
-    if (z < 1.0 / t) {
-        double alpha;
-        do {
-            double e1, e2;
-            do { e1 = orc_expo(s); e2 = orc_expo(s); } while (e1 * e1 > 2.0 * e2 / t);
-            x = 1.0 + e1 * t;
-            x = t / (x * x);
-            alpha = exp(-0.5 * z * z * x);
-        } while (orc_unif(s) > alpha);
+    int upper = p > 0.5;
+    double q = upper ? 1.0 - p : p;                 /* exact for our p = (k + 1/2) 2^-32 */
+    double xx = 2.0 * q - 1.0;                      /* erfinv argument in (-1, 0] */
+    double w = -log(4.0 * q * (1.0 - q)), pl;
+    if (w < 5.0) {
+        w -= 2.5;
+        pl = 2.81022636e-08; pl = 3.43273939e-07 + pl * w; pl = -3.5233877e-06 + pl * w; pl = -4.39150654e-06 + pl * w;
+        pl = 0.00021858087 + pl * w; pl = -0.00125372503 + pl * w; pl = -0.00417768164 + pl * w; pl = 0.246640727 + pl * w;
+        pl = 1.50140941 + pl * w;
     } else {
-        double mu = 1.0 / z;
-        do { x = orc_invgauss(s, mu, 1.0); } while (x > t);
+        w = sqrt(w) - 3.0;
+        pl = -0.000200214257; pl = 0.000100950558 + pl * w; pl = 0.00134934322 + pl * w; pl = -0.00367342844 + pl * w;
+        pl = 0.00573950773 + pl * w; pl = -0.0076224613 + pl * w; pl = 0.00943887047 + pl * w; pl = 1.00167406 + pl * w;
+        pl = 2.83297682 + pl * w;
     }
-    return x;
+    double x = M_SQRT2 * pl * xx;                   /* <= 0 */
+    for (int it = 0; it < 3; ++it) {
+        double cdf = 0.5 * erfc(-x * M_SQRT1_2);
+        double pdf = 0.3989422804014327 * exp(-0.5 * x * x);
+        x -= (cdf - q) / pdf;
+    }
+    return upper ? -x : x;
 }
 
+/* ---- Polya-Gamma PG(1, c): Devroye / Polson-Scott-Windle sampler for J*(1, z = |c|/2), t = 0.64, restated as a
+ * SINGLE-LEVEL rejection sampler in which one attempt consumes exactly one Philox block (u0..u3) and has no inner loop.
+ * Target (unnormalised): f(x) = e^{-z^2 x/2} sum_n (-1)^n a_n(x), a_n as in PSW (2013).  Envelope, three pieces:
+ *   x > t          : a_0(x) e^{-z^2 x/2} = (pi/2) e^{-K x},           K = pi^2/8 + z^2/2, mass p = pi/(2K) e^{-K t}
+ *   x <= t, z < 1/t: a_0(x)            (the Levy / inverse-chi^2_1 kernel), mass q0 = 4 Phi(-1/sqrt t); the factor
+ *                    e^{-z^2 x/2} <= 1 is applied as an acceptance probability
+ *   x <= t, z >= 1/t: a_0(x) e^{-z^2 x/2} extended to ALL x > 0 (the IG(1/z, 1) kernel), mass 2 e^{-z}; draws with
+ *                    x > t are rejected
+ * so the tail is proposed with probability r = p / (p + q_env), q_env = q0 or 2 e^{-z} -- closed form, no normal cdf.
+ *   u0 < r : X = t + (-log u1)/K
+ *   else, z < 1/t : X = 1/Z^2, Z = -Phi^-1(u1 Phi(-1/sqrt t)) (> 1/sqrt t); reject the attempt if u2 > e^{-z^2 X/2}
+ *   else          : X ~ IG(1/z, 1) by Michael-Schucany-Haas with N = Phi^-1(u1), root choice u2; reject if X > t
+ *   then the alternating-series test with V = u3 in ratio form S_n/a_0 = 1 - rho_1 + rho_2 - ...,
+ *        rho_n = a_n/a_0 = (2n+1) e^{-pi^2 n(n+1) X/2} (X > t)  or  (2n+1) e^{-2 n(n+1)/X} (X <= t).
+ * Same law as PolyaGammaPSWSampler(1, eta) (src/Draw.pl.jl:38): PG(1,c) = J*(1,|c|/2)/4. */
+#define ORC_PG_T 0.64
+#define ORC_PG_Q0 0.42259909466742100 /* 4 Phi(-1/sqrt(t)) = 4 Phi(-1.25) */
+#define ORC_PG_PHI_M 0.10564977366685525 /* Phi(-1.25) */
+
+static inline double orc_u32_to_unif(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
+
+/* probability that an attempt proposes from the exponential tail */
+static inline double orc_pg_tail_weight(double z)
+{
+    const double t = ORC_PG_T;
+    double K = 0.125 * ORC_PI * ORC_PI + 0.5 * z * z;
+    double p = ORC_PI / (2.0 * K) * exp(-K * t);
+    double qenv = (z < 1.0 / t) ? ORC_PG_Q0 : 2.0 * exp(-z);
+    return p / (p + qenv);
+}
+
+/* one attempt; returns 1 and sets *out = X/4 on acceptance */
+static inline int orc_pg1_attempt(double z, const uint32_t w[4], double* out)
+{
+    const double t = ORC_PG_T;
+    double K = 0.125 * ORC_PI * ORC_PI + 0.5 * z * z;
+    double r = orc_pg_tail_weight(z);
+    double u0 = orc_u32_to_unif(w[0]), u1 = orc_u32_to_unif(w[1]), u2 = orc_u32_to_unif(w[2]), V = orc_u32_to_unif(w[3]);
+    double x;
+    if (u0 < r) {
+        x = t + (-log(u1)) / K;
+    } else if (z < 1.0 / t) {
+        double zt = -orc_ndtri(u1 * ORC_PG_PHI_M);
+        x = 1.0 / (zt * zt);
+        if (u2 > exp(-0.5 * z * z * x)) return 0;
+    } else {
+        double mu = 1.0 / z, n = orc_ndtri(u1);
+        double ww = mu * n * n;
+        double sq = sqrt(ww) * sqrt(4.0 + ww), den = sq + ww;
+        double q = den > 0.0 ? 2.0 * sqrt(ww) / den : 1.0;
+        double x1 = mu * q * q;
+        x = (u2 >= mu / (mu + x1)) ? mu * mu / x1 : x1;
+        if (x > t) return 0;
+    }
+    double S = 1.0;
+    for (int n = 1; n <= 200; ++n) {
+        double nn = (double)n * (double)(n + 1);
+        double rho = (2.0 * n + 1.0) * (x > t ? exp(-0.5 * ORC_PI * ORC_PI * nn * x) : exp(-2.0 * nn / x));
+        if (n & 1) { S -= rho; if (V <= S) { *out = 0.25 * x; return 1; } }
+        else       { S += rho; if (V > S) return 0; }
+    }
+    *out = 0.25 * x; return 1; /* unreachable guard */
+}
+
+/* draw for stream (site, i, j, sweep): attempt k uses Philox block k of that stream */
 static inline double orc_pg1(orc_stream* s, double c)
 {
-    const double t = ORC_PG_T;
     double z = 0.5 * fabs(c);
-    double fz = 0.125 * ORC_PI * ORC_PI + 0.5 * z * z;
-    double r = orc_pg_mass_texpon(z);
     for (;;) {
-        double x;
-        if (orc_unif(s) < r) x = t + orc_expo(s) / fz;
-        else x = orc_pg_rtigauss(s, z);
-        double S = orc_pg_an(0, x);
-        double y = orc_unif(s) * S;
-        int n = 0;
-        for (;;) {
-            ++n;
-            if (n & 1) { S -= orc_pg_an(n, x); if (y <= S) return 0.25 * x; }
-            else       { S += orc_pg_an(n, x); if (y > S) break; }
-            if (n > 200) return 0.25 * x; /* unreachable guard */
-        }
+        uint32_t w[4];
+        w[0] = orc_u32(s); w[1] = orc_u32(s); w[2] = orc_u32(s); w[3] = orc_u32(s);
+        double out;
+        if (orc_pg1_attempt(z, w, &out)) return out;
     }
 }
 
