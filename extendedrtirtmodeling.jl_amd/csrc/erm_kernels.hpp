@@ -59,7 +59,8 @@ template <typename real> struct PassArgs {
     const double* par; const double* cst; double* slab; const Ctl* ctl;
     double* sum_theta; double* sum_zeta; double* sum_nu;
     real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] or nullptr
-    long long N; int J; int nFeat; int W; int logW; int IPL;
+    long long N; long long rows_per_block;          // each workgroup owns rows [b*rpb, (b+1)*rpb)
+    int J; int nFeat; int W; int logW; int IPL;
     int mode;             // 0 = prologue (no theta/zeta draws, no LL, no trace), 1 = full sweep pass
     uint32_t chain; uint64_t seed; double k1, k2;
 };
@@ -70,13 +71,21 @@ template <typename T> __device__ __forceinline__ T bfly_sum(T v, int lo, int hi)
     return v;
 }
 
-__device__ __forceinline__ float  log1pexp_r(float x)  { return x > 0.f ? x + log1pf(__expf(-x)) : log1pf(__expf(x)); }
+// log(1 + e^x)
+__device__ __forceinline__ float  log1pexp_r(float x)  { return fmaxf(x, 0.f) + r_log(1.f + r_exp(-fabsf(x))); }
 __device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
 constexpr double LOG_2PI = 1.8378770664093454836;
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Row pass.  blockDim.x = 64 * nWaves.  Dynamic LDS: item arrays (real), structural scalars, per-wave accumulators.
+// Row pass.  blockDim.x = 64 * nWaves; workgroup b owns a contiguous range of subjects.
+//   phase 1 (lane (r, s) of a wave: subject r of the wave's group, items s, s+W, ...):
+//       row sums over omega_t / Y / logT, theta_t and zeta_t draws, per-subject outputs and global statistics, then the
+//       persistent-lane loop that draws omega_{t+1};
+//   barrier (everything the workgroup wrote for its own subjects is visible to all its waves);
+//   phase 2 (lane = item j, waves stride over the workgroup's subjects): per-cell log-likelihood terms and the item
+//       statistics, accumulated in fp64 REGISTERS with no cross-lane traffic; CrossQr's per-cell nu_{t+1} draw lives here.
+//   epilogue: fixed-order sum of the waves' accumulators -> this workgroup's slab row.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MODEL, typename real, int PHASE>
 __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(PassArgs<real> A)
@@ -90,8 +99,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     const int s = lane & (W - 1), r = lane >> A.logW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* sh_d = reinterpret_cast<double*>(smem);
-    double* sh_struct = sh_d;                                   // 8 + 2*PMAX doubles
+    double* sh_struct = reinterpret_cast<double*>(smem);        // 8 + 2*PMAX doubles
     double* sh_acc = sh_struct + 8 + 2 * PMAX;                  // [nWaves][NSTAT][J]
     double* sh_gacc = sh_acc + (size_t)nWaves * NSTAT * J;      // [nWaves][NG][R]
     double* sh_ll = sh_gacc + (size_t)nWaves * NG * R;          // [nWaves]
@@ -128,16 +136,21 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     double* gacc = sh_gacc + (size_t)wave * NG * R;
     double ll = 0.0;
 
-    const long long nGroups = (A.N + R - 1) / R;
-    for (long long g = (long long)blockIdx.x * nWaves + wave; g < nGroups; g += (long long)gridDim.x * nWaves) {
-        const long long i = g * R + r;
-        const bool rowok = i < A.N;
-        const size_t base = (size_t)(rowok ? i : 0) * J;
+    const long long row0 = (long long)blockIdx.x * A.rows_per_block;
+    const long long row1 = (row0 + A.rows_per_block < A.N) ? row0 + A.rows_per_block : A.N;
 
-        // ---------------- row phase: sums over the subject's items
+    // =================================================================================================== phase 1
+    for (long long g0 = row0 + (long long)wave * R; g0 < row1; g0 += (long long)nWaves * R) {
+        const long long i = g0 + r;
+        const bool rowok = i < row1;
+        const size_t base = (size_t)(rowok ? i : row0) * J;
+
+        // ---------------- sums over the subject's items
         real sA = 0, sB = 0, sC = 0, sD = 0;
+        real th = rowok ? A.theta[i] : real(0);
+        real ze = (MODEL != MLIRT && rowok) ? A.zeta[i] : real(0);
         if (PHASE == 0) {
-            if (rowok) for (int k = 0; k < IPL; ++k) {
+            if (rowok && A.mode == 1) for (int k = 0; k < IPL; ++k) {
                 const int j = s + W * k;
                 if (j < J) {
                     const real w = A.omega[base + j];
@@ -150,12 +163,11 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             sA = bfly_sum(sA, 1, W); sB = bfly_sum(sB, 1, W);
             if (MODEL == RTIRT || MODEL == LATENTQR) sC = bfly_sum(sC, 1, W);
         } else {   // CrossQr pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202)
-            const real th = rowok ? A.theta[i] : real(0);
-            if (rowok) for (int k = 0; k < IPL; ++k) {
+            if (rowok && A.mode == 1) for (int k = 0; k < IPL; ++k) {
                 const int j = s + W * k;
                 if (j < J) {
                     const real nu = A.nu[base + j];
-                    const real iden = sh_isig[j] / (k2 * nu);
+                    const real iden = r_div(sh_isig[j], k2 * nu);
                     sD += iden;
                     sC += (sh_lamc[j] - A.C[base + j] - th * sh_rho[j] + k1 * nu) * iden;
                 }
@@ -164,66 +176,57 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         }
 
         // ---------------- row draws (computed redundantly by the W lanes of the row)
-        real th = rowok ? A.theta[i] : real(0);
-        real ze = (MODEL != MLIRT && rowok) ? A.zeta[i] : real(0);
-        real nu_row = real(1), xb5 = real(0);
-        real x[PMAX];                                       // design row [1 X], statically indexed
-#pragma unroll
-        for (int u = 0; u < PMAX; ++u) x[u] = (u == 0) ? real(1) : ((u < p && rowok) ? A.X[(size_t)i * A.nFeat + (u - 1)] : real(0));
-
+        real nu_row = real(1), xb5 = real(0), mu0a = real(0), mu0b = real(0);
+        if (rowok && PHASE == 0 && MODEL != CROSSQR) {
+            // x_i' beta for the columns this model needs ([1 X] design; LatentQr adds theta below)
+            for (int u = 0; u < p; ++u) {
+                const real xu = (u == 0) ? real(1) : A.X[(size_t)i * A.nFeat + (u - 1)];
+                mu0a += xu * (real)beta[u];
+                if (MODEL == RTIRT) mu0b += xu * (real)beta[PMAX + u];
+            }
+        }
         if (A.mode == 1 && rowok) {
             if (PHASE == 0) {
                 // theta: src/Draw.pl.jl:49-62 (prior x*beta[:,1]) / :67-80 (Null prior)
-                real mu0 = 0;
-                if (MODEL == MLIRT || MODEL == RTIRT) {
-#pragma unroll
-                    for (int u = 0; u < PMAX; ++u) if (u < p) mu0 += x[u] * (real)beta[u];
-                }
-                const real parV = real(1) / (real(1) / sig11 + sA);
-                const real parM = parV * (mu0 / sig11 + sB);
+                const real mu0 = (MODEL == MLIRT || MODEL == RTIRT) ? mu0a : real(0);
+                const real parV = r_rcp(r_rcp(sig11) + sA);
+                const real parM = parV * (r_div(mu0, sig11) + sB);
                 Stream st(A.seed, A.chain, SITE_THETA, (uint32_t)i, 0u, sweep);
                 th = parM + r_sqrt(parV) * normal<real>(st);
             }
             if (MODEL == RTIRT || MODEL == LATENTQR) {
                 // zeta: src/Draw.pl.jl:132-141 / :161-174
-                real mu0 = 0, s0 = sig22;
-                if (MODEL == RTIRT) {
-#pragma unroll
-                    for (int u = 0; u < PMAX; ++u) if (u < p) mu0 += x[u] * (real)beta[PMAX + u];
-                } else {
+                real mu0 = mu0b, s0 = sig22;
+                if (MODEL == LATENTQR) {
                     nu_row = A.nu[i];
-#pragma unroll
-                    for (int u = 0; u < PMAX; ++u) if (u < p) xb5 += x[u] * (real)beta[u];
-                    xb5 += th * (real)beta[p];
+                    xb5 = mu0a + th * (real)beta[p];
                     mu0 = xb5 + k1 * nu_row;
                     s0 = sig22 * (k2 * nu_row);
                 }
-                const real parV = real(1) / (real(1) / s0 + sum_isig);
-                const real parM = parV * (mu0 / s0 + sC);
+                const real parV = r_rcp(r_rcp(s0) + sum_isig);
+                const real parM = parV * (r_div(mu0, s0) + sC);
                 Stream st(A.seed, A.chain, SITE_ZETA, (uint32_t)i, 0u, sweep);
                 ze = parM + r_sqrt(parV) * normal<real>(st);
             }
             if (MODEL == CROSSQR && PHASE == 1) {
                 // zeta: src/Draw.pl.jl:192-206 (zero prior mean, prior variance Sigp[2,2])
-                const real parV = real(1) / (real(1) / sig22 + sD);
+                const real parV = r_rcp(r_rcp(sig22) + sD);
                 const real parM = parV * sC;
                 Stream st(A.seed, A.chain, SITE_ZETA, (uint32_t)i, 0u, sweep);
                 ze = parM + r_sqrt(parV) * normal<real>(st);
             }
         } else if (MODEL == LATENTQR && rowok) {
-            nu_row = A.nu ? A.nu[i] : real(1);
-#pragma unroll
-            for (int u = 0; u < PMAX; ++u) if (u < p) xb5 += x[u] * (real)beta[u];
-            xb5 += th * (real)beta[p];
+            nu_row = A.nu[i];
+            xb5 = mu0a + th * (real)beta[p];
         }
 
-        // ---------------- per-row outputs, structural log-likelihood, next-sweep nu (LatentQr), global statistics
+        // ---------------- per-subject outputs, structural log-likelihood, next-sweep nu (LatentQr), global statistics
         real nu_next = real(1);
         if (MODEL == LATENTQR && rowok) {
             // nu_{t+1}: src/Draw.pl.jl:325-343 (depends on zeta_t, theta_t, beta_t, Sigp_t only)
             const real den = r_sqrt(sig22 * k2);
-            const real parA = r_abs(ze - xb5) / den;
-            const real parB = r_sqrt(real(2) * k2 + k1 * k1) / den;
+            const real parA = r_div(r_abs(ze - xb5), den);
+            const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
             Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, 0u, sweep + 1u);
             nu_next = qr_weight<real>(st, parA, parB);
         }
@@ -241,20 +244,12 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 }
                 // structural log-likelihood terms (src/GibbsRtIrt.pl.jl:201,269; src/GibbsRtIrtLatent.pl.jl:261)
                 if (MODEL == MLIRT) {
-                    real mu = 0;
-#pragma unroll
-                    for (int u = 0; u < PMAX; ++u) if (u < p) mu += x[u] * (real)beta[u];
-                    const real e = th - mu;
+                    const real e = th - mu0a;
                     ll += -0.5 * LOG_2PI - 0.5 * (double)(e * e);
                 } else if (MODEL == RTIRT || (MODEL == CROSSQR && PHASE == 1)) {
-                    real m0 = 0, m1 = 0;
-                    if (MODEL == RTIRT) {
-#pragma unroll
-                        for (int u = 0; u < PMAX; ++u) if (u < p) { m0 += x[u] * (real)beta[u]; m1 += x[u] * (real)beta[PMAX + u]; }
-                    }
                     const double s00 = sh_struct[0], s10 = sh_struct[1], s01 = sh_struct[2], s11 = sh_struct[3];
                     const double det = s00 * s11 - s10 * s01;
-                    const double e0 = (double)(th - m0), e1 = (double)(ze - m1);
+                    const double e0 = (double)(th - mu0a), e1 = (double)(ze - mu0b);
                     const double q = (s11 * e0 * e0 - (s10 + s01) * e0 * e1 + s00 * e1 * e1) / det;
                     ll += -LOG_2PI - 0.5 * log(det) - 0.5 * q;
                 } else if (MODEL == LATENTQR) {
@@ -269,22 +264,21 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             // global statistics for the next tiny step (lane-private LDS slots: gacc[g][r])
             if (PHASE == 0 && MODEL != CROSSQR) {
                 int o = 0;
-#pragma unroll
-                for (int u = 0; u < PMAX; ++u) if (u < p) gacc[(o + u) * R + r] += (double)x[u] * (double)th;
-                o += p;
+                for (int u = 0; u < p; ++u) {
+                    const double xu = (u == 0) ? 1.0 : (double)A.X[(size_t)i * A.nFeat + (u - 1)];
+                    gacc[u * R + r] += xu * (double)th;
+                    if (MODEL == RTIRT) gacc[(p + u) * R + r] += xu * (double)ze;
+                    if (MODEL == LATENTQR) gacc[(p + 1 + u) * R + r] += xu * ((double)ze - (double)k1 * (double)nu_next);
+                }
+                o = p;
                 if (MODEL == RTIRT) {
-#pragma unroll
-                    for (int u = 0; u < PMAX; ++u) if (u < p) gacc[(o + u) * R + r] += (double)x[u] * (double)ze;
                     o += p;
                     gacc[(o + 0) * R + r] += (double)th * (double)th;
                     gacc[(o + 1) * R + r] += (double)th * (double)ze;
                     gacc[(o + 2) * R + r] += (double)ze * (double)ze;
                 } else if (MODEL == LATENTQR) {
                     const double uu = (double)ze - (double)k1 * (double)nu_next;
-                    gacc[(o + 0) * R + r] += (double)th * (double)th; o += 1;
-#pragma unroll
-                    for (int u = 0; u < PMAX; ++u) if (u < p) gacc[(o + u) * R + r] += (double)x[u] * uu;
-                    o += p;
+                    gacc[(o + 0) * R + r] += (double)th * (double)th; o += 1 + p;
                     gacc[(o + 0) * R + r] += (double)th * uu;
                     gacc[(o + 1) * R + r] += uu * uu;
                     gacc[(o + 2) * R + r] += (double)nu_next;
@@ -296,10 +290,10 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             if (MODEL == CROSSQR && PHASE == 1) gacc[0 * R + r] += (double)ze * (double)ze;
         }
 
-        // ---------------- cell phase A (PHASE 0): omega_{t+1} | theta_t, a_t, b_t  (src/Draw.pl.jl:36-40)
-        // Persistent lanes: every lane walks through its own IPL cells, one single-block PG attempt per trip, and moves on
-        // to its next cell as soon as a draw is accepted, so a wave pays max-over-lanes of the TOTAL attempts rather than the
-        // sum over cells of the max.  Attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
+        // ---------------- omega_{t+1} | theta_t, a_t, b_t  (src/Draw.pl.jl:36-40), persistent lanes:
+        // every lane walks through its own IPL cells, one single-block PG attempt per trip, and moves on to its next cell as
+        // soon as a draw is accepted, so a wave pays the max over lanes of the TOTAL attempts rather than the sum over cells of
+        // the max.  Attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
         if constexpr (PHASE == 0) {
             int j = s;
             bool active = rowok && j < J;
@@ -311,8 +305,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     uint32_t w0, w1, w2, w3;
                     philox4x32_10((uint32_t)i, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
                     real w;
-                    const bool acc = pg1_attempt<real>(z, w0, w1, w2, w3, w);
-                    if (acc || att + 1u >= (uint32_t)MAX_TRIES) {
+                    const bool acc_ = pg1_attempt<real>(z, w0, w1, w2, w3, w);
+                    if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
                         A.omega[base + j] = w;
                         j += W; att = 0;
                         active = j < J;
@@ -321,69 +315,77 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 }
             }
         }
+    }
+    __syncthreads();
 
-        // ---------------- cell phase B: log-likelihood, next-sweep nu (CrossQr pass B), item statistics (lockstep over k)
-        for (int k = 0; k < IPL; ++k) {
-            const int j = s + W * k;
-            const bool ok = rowok && j < J;
-            real v[NSTAT];
+    // =================================================================================================== phase 2
+    for (int cb = 0; cb * 64 < J; ++cb) {
+        const int j = cb * 64 + lane;
+        const bool jv = j < J;
+        const real a = jv ? sh_a[j] : real(0), b = jv ? sh_b[j] : real(0);
+        const real lamc = jv ? sh_lamc[j] : real(0), isig = jv ? sh_isig[j] : real(1), lsig = jv ? sh_lsig[j] : real(0);
+        const real rho = jv ? sh_rho[j] : real(0);
+        double S[NSTAT];
 #pragma unroll
-            for (int q = 0; q < NSTAT; ++q) v[q] = 0;
-            if (ok) {
+        for (int q = 0; q < NSTAT; ++q) S[q] = 0.0;
+        double llc = 0.0;
+#pragma unroll 2
+        for (long long i = row0 + wave; i < row1; i += nWaves) {
+            const real th = A.theta[i];
+            const real ze = (MODEL != MLIRT) ? A.zeta[i] : real(0);
+            if (jv) {
+                const size_t e = (size_t)i * J + j;
                 if constexpr (PHASE == 0) {
-                    const real a = sh_a[j], b = sh_b[j];
-                    const real eta = a * (th - b);
-                    const bool y = A.Y[base + j] != 0;
-                    const real kap = y ? real(0.5) : real(-0.5);
+                    const real w = A.omega[e];
+                    const bool y = A.Y[e] != 0;
                     real c = 0;
-                    if (MODEL != MLIRT) c = A.C[base + j];
+                    if (MODEL != MLIRT) c = A.C[e];
+                    const double wd = (double)w, thd = (double)th;
+                    S[0] += wd; S[1] += wd * thd; S[2] += wd * thd * thd; S[3] += y ? 0.5 * thd : -0.5 * thd;
+                    if constexpr (MODEL == RTIRT || MODEL == LATENTQR) S[4] += (double)c * (double)ze;
                     if (A.mode == 1) {
-                        ll += (double)((y ? eta : real(0)) - log1pexp_r(eta));
+                        const real eta = a * (th - b);
+                        real t = (y ? eta : real(0)) - log1pexp_r(eta);
                         if (MODEL == RTIRT || MODEL == LATENTQR) {
-                            const real e = c + ze - sh_lamc[j];
-                            ll += -0.5 * LOG_2PI - 0.5 * (double)(sh_lsig[j] + e * e * sh_isig[j]);
+                            const real er = c + ze - lamc;
+                            t += real(-0.5) * ((real)LOG_2PI + lsig + er * er * isig);
                         }
+                        llc += (double)t;
                     }
-                    const real w = A.omega[base + j];      // written by this lane in phase A
-                    v[0] = w; v[1] = w * th; v[2] = w * th * th; v[3] = kap * th;
-                    if constexpr (MODEL == RTIRT || MODEL == LATENTQR) v[4] = c * ze;
                     if constexpr (MODEL == CROSSQR) {
                         // statistics for lambda_t, sig2t_t (src/Draw.pl.jl:246-247, 285) with nu_t, zeta_{t-1}, theta_t, rho_t
-                        const real nu = A.nu[base + j];
-                        const real rr = c + ze + th * sh_rho[j] - k1 * nu;
-                        const real inu = real(1) / nu;
-                        v[4] = inu; v[5] = rr * inu; v[6] = rr * rr * inu; v[7] = nu;
+                        const real nu = A.nu[e];
+                        const real rr = c + ze + th * rho - k1 * nu;
+                        const double inu = 1.0 / (double)nu, rd = (double)rr;
+                        S[4] += inu; S[5] += rd * inu; S[6] += rd * rd * inu; S[7] += (double)nu;
                     }
                 } else {
                     // CrossQr pass B: RT log-likelihood with nu_t, then nu_{t+1} (src/Draw.pl.jl:303-320) and rho statistics (:484-485)
-                    const real c = A.C[base + j];
-                    const real nu = A.nu[base + j];
-                    const real rho = sh_rho[j];
+                    const real c = A.C[e];
+                    const real nu = A.nu[e];
                     if (A.mode == 1) {
-                        const real var_ = k2 * nu;                                   // times sig2t_j
-                        const real e = c - sh_lamc[j] + ze + th * rho - k1 * nu;   // logT - mu_t
-                        ll += -0.5 * LOG_2PI - 0.5 * (double)(sh_lsig[j] + r_log(var_) + e * e * sh_isig[j] / var_);
-                        if (post_burn && A.sum_nu) A.sum_nu[base + j] += (double)nu;
+                        const real var_ = k2 * nu;                               // times sig2t_j
+                        const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
+                        llc += (double)(real(-0.5) * ((real)LOG_2PI + lsig + r_log(var_) + r_div(er * er * isig, var_)));
+                        if (post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
                     }
-                    const real den = r_sqrt(k2) / r_sqrt(sh_isig[j]);               // sqrt(sig2t k2)
-                    const real parA = r_abs(c - sh_lamc[j] + ze + th * rho) / den;
-                    const real parB = r_sqrt(real(2) * k2 + k1 * k1) / den;
+                    const real den = r_div(r_sqrt(k2), r_sqrt(isig));            // sqrt(sig2t k2)
+                    const real parA = r_div(r_abs(c - lamc + ze + th * rho), den);
+                    const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
                     Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, (uint32_t)j, sweep + 1u);
                     const real nun = qr_weight<real>(st, parA, parB);
-                    A.nu[base + j] = nun;
-                    const real inu = real(1) / nun;
-                    v[0] = th * th * inu;
-                    v[1] = th * (sh_lamc[j] - ze - c + k1 * nun) * inu;
+                    A.nu[e] = nun;
+                    const double inu = 1.0 / (double)nun, thd = (double)th;
+                    S[0] += thd * thd * inu;
+                    S[1] += thd * (double)(lamc - ze - c + k1 * nun) * inu;
                 }
             }
-            // sum over the R subjects of the wave, then accumulate in the wave's fp64 LDS slots
-#pragma unroll
-            for (int q = 0; q < NSTAT; ++q) v[q] = bfly_sum(v[q], W, 64);
-            if (r == 0 && j < J) {
-#pragma unroll
-                for (int q = 0; q < NSTAT; ++q) acc[q * J + j] += (double)v[q];
-            }
         }
+        if (jv) {
+#pragma unroll
+            for (int q = 0; q < NSTAT; ++q) acc[q * J + j] = S[q];
+        }
+        ll += llc;
     }
 
     // ---------------- block epilogue: fixed-order reduction of the wave accumulators into this block's slab row

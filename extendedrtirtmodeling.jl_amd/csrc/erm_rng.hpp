@@ -25,22 +25,22 @@ enum Site : uint32_t {
 };
 
 // ---- precision-generic math wrappers -------------------------------------------------------
-__device__ __forceinline__ float  r_exp(float x)  { return __expf(x); }
+// fp32 uses the hardware-rate transcendental instructions (v_exp_f32, v_log_f32, v_rcp_f32, v_sqrt_f32, v_cos_f32: ~1 ulp),
+// never the IEEE-exact expansion sequences: the cell path is VALU-issue-bound and these are its inner loop.
+__device__ __forceinline__ float  r_exp(float x)  { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ double r_exp(double x) { return exp(x); }
-__device__ __forceinline__ float  r_log(float x)  { return __logf(x); }
+__device__ __forceinline__ float  r_log(float x)  { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ double r_log(double x) { return log(x); }
-__device__ __forceinline__ float  r_sqrt(float x)  { return __fsqrt_rn(x); }
+__device__ __forceinline__ float  r_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ float  r_rcp(float x)  { return __frcp_rn(x); }
+__device__ __forceinline__ float  r_rcp(float x)  { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double r_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float  r_div(float a, float b)  { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double r_div(double a, double b) { return a / b; }
 __device__ __forceinline__ float  r_abs(float x)  { return fabsf(x); }
 __device__ __forceinline__ double r_abs(double x) { return fabs(x); }
-__device__ __forceinline__ float  r_cospi(float x)  { return cospif(x); }
-__device__ __forceinline__ double r_cospi(double x) { return cospi(x); }
-__device__ __forceinline__ float  r_erfc(float x)  { return erfcf(x); }
-__device__ __forceinline__ double r_erfc(double x) { return erfc(x); }
-__device__ __forceinline__ float  r_log1p(float x)  { return log1pf(x); }
-__device__ __forceinline__ double r_log1p(double x) { return log1p(x); }
+__device__ __forceinline__ float  r_cos2pi(float x)  { return __builtin_amdgcn_cosf(x); }     // v_cos_f32 takes revolutions
+__device__ __forceinline__ double r_cos2pi(double x) { return cospi(2.0 * x); }
 
 template <typename real> struct Const;
 template <> struct Const<float> {
@@ -105,7 +105,7 @@ template <typename real> __device__ __forceinline__ real expo(Stream& s) { retur
 template <typename real> __device__ __forceinline__ real normal(Stream& s)
 {
     const real u1 = uniform<real>(s), u2 = uniform<real>(s);
-    return r_sqrt(real(-2) * r_log(u1)) * r_cospi(real(2) * u2);
+    return r_sqrt(real(-2) * r_log(u1)) * r_cos2pi(u2);
 }
 
 // IG(mu, lambda), Michael-Schucany-Haas with the cancellation-free smaller root
@@ -115,18 +115,18 @@ template <typename real> __device__ __forceinline__ real invgauss(Stream& s, rea
     const real w = mu * nrm * nrm;
     const real sq = r_sqrt(w) * r_sqrt(real(4) * lambda + w);
     const real den = sq + w;
-    const real q = den > real(0) ? real(2) * r_sqrt(lambda * w) / den : real(1);   // w -> 0: x1 -> mu
+    const real q = den > real(0) ? r_div(real(2) * r_sqrt(lambda * w), den) : real(1);   // w -> 0: x1 -> mu
     const real x1 = mu * q * q;
     const real u = uniform<real>(s);
-    return (u >= mu / (mu + x1)) ? mu * mu / x1 : x1;
+    return (u >= r_div(mu, mu + x1)) ? r_div(mu * mu, x1) : x1;
 }
 
 // nu = clamp(1 / IG(clamp(parB/parA, 1e-10, Inf), parB^2), 1e-10, 1e10): src/Draw.pl.jl:310-318, 333-341
 template <typename real> __device__ __forceinline__ real qr_weight(Stream& s, real parA, real parB)
 {
-    real mu = parB / parA;
+    real mu = r_div(parB, parA);
     mu = mu < real(1e-10) ? real(1e-10) : mu;
-    real nu = real(1) / invgauss<real>(s, mu, parB * parB);
+    real nu = r_rcp(invgauss<real>(s, mu, parB * parB));
     nu = nu < real(1e-10) ? real(1e-10) : (nu > real(1e10) ? real(1e10) : nu);
     return nu;
 }
@@ -142,7 +142,7 @@ __device__ __forceinline__ float giles_erfinv_poly(float w)
         pl = fmaf(pl, w, 0.00021858087f); pl = fmaf(pl, w, -0.00125372503f); pl = fmaf(pl, w, -0.00417768164f); pl = fmaf(pl, w, 0.246640727f);
         pl = fmaf(pl, w, 1.50140941f);
     } else {
-        w = __fsqrt_rn(w) - 3.0f;
+        w = __builtin_amdgcn_sqrtf(w) - 3.0f;
         pl = -0.000200214257f; pl = fmaf(pl, w, 0.000100950558f); pl = fmaf(pl, w, 0.00134934322f); pl = fmaf(pl, w, -0.00367342844f);
         pl = fmaf(pl, w, 0.00573950773f); pl = fmaf(pl, w, -0.0076224613f); pl = fmaf(pl, w, 0.00943887047f); pl = fmaf(pl, w, 1.00167406f);
         pl = fmaf(pl, w, 2.83297682f);
@@ -152,7 +152,7 @@ __device__ __forceinline__ float giles_erfinv_poly(float w)
 __device__ __forceinline__ float ndtri(float p)
 {
     const float x = 2.0f * p - 1.0f;
-    const float w = -__logf(4.0f * p * (1.0f - p));
+    const float w = -r_log(4.0f * p * (1.0f - p));
     return 1.41421356237f * giles_erfinv_poly(w) * x;
 }
 // fp64: the same polynomial as a starting point, polished by three Newton steps on Phi(x) = q in the lower tail
@@ -196,9 +196,9 @@ template <> __device__ __forceinline__ float word_to_unif<float>(uint32_t w) { r
 template <typename real> __device__ __forceinline__ real pg_tail_weight(real z, real K)
 {
     const real t = real(0.64);
-    const real p = Const<real>::PI / (real(2) * K) * r_exp(-K * t);
-    const real qenv = (z < real(1) / t) ? real(0.42259909466742100) : real(2) * r_exp(-z);
-    return p / (p + qenv);
+    const real p = r_div(Const<real>::PI, real(2) * K) * r_exp(-K * t);
+    const real qenv = (z < real(1.5625)) ? real(0.42259909466742100) : real(2) * r_exp(-z);
+    return r_div(p, p + qenv);
 }
 
 template <typename real>
@@ -212,24 +212,24 @@ __device__ __forceinline__ bool pg1_attempt(real z, uint32_t w0, uint32_t w1, ui
     real x;
     bool ok = true;
     if (u0 < r) {
-        x = t - r_log(u1) / K;
-    } else if (z < real(1) / t) {
+        x = t - r_div(r_log(u1), K);
+    } else if (z < real(1.5625)) {
         const real zt = ndtri(u1 * real(0.10564977366685525));       // <= -1/sqrt(t)
-        x = real(1) / (zt * zt);
+        x = r_rcp(zt * zt);
         ok = !(u2 > r_exp(real(-0.5) * z * z * x));
     } else {
-        const real mu = real(1) / z, nrm = ndtri(u1);
+        const real mu = r_rcp(z), nrm = ndtri(u1);
         const real ww = mu * nrm * nrm;
         const real sq = r_sqrt(ww) * r_sqrt(real(4) + ww), den = sq + ww;
-        const real q = den > real(0) ? real(2) * r_sqrt(ww) / den : real(1);
+        const real q = den > real(0) ? r_div(real(2) * r_sqrt(ww), den) : real(1);
         const real x1 = mu * q * q;
-        x = (u2 >= mu / (mu + x1)) ? mu * mu / x1 : x1;
+        x = (u2 >= r_div(mu, mu + x1)) ? r_div(mu * mu, x1) : x1;
         ok = !(x > t);
     }
     out = real(0.25) * x;
     if (!ok) return false;
     // alternating series: accept at odd n if V <= S_n, reject at even n if V > S_n
-    const real e1 = (x > t) ? real(-0.5) * PI * PI * x : real(-2) / x;     // rho_n = (2n+1) exp(n(n+1) e1)
+    const real e1 = (x > t) ? real(-0.5) * PI * PI * x : real(-2) * r_rcp(x);     // rho_n = (2n+1) exp(n(n+1) e1)
     real S = real(1) - real(3) * r_exp(real(2) * e1);
     if (V <= S) return true;
     for (int n = 2; n <= 200; ++n) {

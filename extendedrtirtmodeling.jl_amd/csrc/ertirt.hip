@@ -91,6 +91,7 @@ template <typename real> struct Engine : EngineBase {
     int64_t rows_cap = 0;
     bool has_data = false;
     int W = 8, logW = 3, IPL = 1, block_threads = 1024, grid_blocks = 256;
+    int64_t rows_per_block = 0;
     size_t lds_pass[2] = {0, 0};
     int ns[2] = {0, 0};
     uint32_t sweeps_total = 0;
@@ -179,6 +180,9 @@ template <typename real> struct Engine : EngineBase {
         const int per_cu = std::max(1, 16 / nWaves);
         grid_blocks = cfg.grid_blocks > 0 ? cfg.grid_blocks : (int)std::min<int64_t>(need, (int64_t)cu_count * per_cu);
         if (grid_blocks < 1) grid_blocks = 1;
+        // each workgroup owns a contiguous range of subjects (a multiple of R so that wave groups never straddle two workgroups)
+        rows_per_block = ((N + grid_blocks - 1) / grid_blocks + R - 1) / R * R;
+        grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
         for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
         if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads");
 
@@ -270,7 +274,7 @@ template <typename real> struct Engine : EngineBase {
         a.ctl = dCtl.as<Ctl>();
         a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
         a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
-        a.N = N; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode;
+        a.N = N; a.rows_per_block = rows_per_block; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode;
         a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164

@@ -167,7 +167,7 @@ static inline double orc_pg_tail_weight(double z)
     const double t = ORC_PG_T;
     double K = 0.125 * ORC_PI * ORC_PI + 0.5 * z * z;
     double p = ORC_PI / (2.0 * K) * exp(-K * t);
-    double qenv = (z < 1.0 / t) ? ORC_PG_Q0 : 2.0 * exp(-z);
+    double qenv = (z < 1.5625) ? ORC_PG_Q0 : 2.0 * exp(-z); /* 1/t */
     return p / (p + qenv);
 }
 
@@ -181,7 +181,7 @@ static inline int orc_pg1_attempt(double z, const uint32_t w[4], double* out)
     double x;
     if (u0 < r) {
         x = t + (-log(u1)) / K;
-    } else if (z < 1.0 / t) {
+    } else if (z < 1.5625) {
         double zt = -orc_ndtri(u1 * ORC_PG_PHI_M);
         x = 1.0 / (zt * zt);
         if (u2 > exp(-0.5 * z * z * x)) return 0;
