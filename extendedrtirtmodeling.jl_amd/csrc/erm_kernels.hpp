@@ -30,10 +30,12 @@ struct Ctl {
     uint32_t err;         // sticky non-finite flag
 };
 
-// parameter block written by the tiny step (fp64): a, b, lambda, sig2t, rho : 5 x J, then Sigp(4), beta(2*PMAX)
+// parameter block written by the tiny step (fp64): a, b, lambda, sig2t, rho : 5 x J, then Sigp(4), beta(2*PMAX),
+// then derived scalars: [0] sum_j 1/sig2t_j
 __host__ __device__ inline int par_off_sigp(int J) { return 5 * J; }
 __host__ __device__ inline int par_off_beta(int J) { return 5 * J + 4; }
-__host__ __device__ inline int par_size(int J) { return 5 * J + 4 + 2 * PMAX; }
+__host__ __device__ inline int par_off_derived(int J) { return 5 * J + 4 + 2 * PMAX; }
+__host__ __device__ inline int par_size(int J) { return 5 * J + 4 + 2 * PMAX + 4; }
 
 // data constants (fp64): K0[J], m[J] (column means of logT), csq[J] (sum of squared centred logT), muLam, sdLam,
 // XtX[PMAX*PMAX] = x'x with x = [1 X] (iteration-invariant, src/Draw.pl.jl:383-386 recomputes it every sweep), XtXinv[PMAX*PMAX]
@@ -60,10 +62,26 @@ template <typename real> struct PassArgs {
     double* sum_theta; double* sum_zeta; double* sum_nu;
     real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] or nullptr
     long long N; long long rows_per_block;          // each workgroup owns rows [b*rpb, (b+1)*rpb)
+    int rows_per_wave;                              // capacity of a wave's theta cache: ceil(rpb / nWaves)
     int J; int nFeat; int W; int logW; int IPL;
     int mode;             // 0 = prologue (no theta/zeta draws, no LL, no trace), 1 = full sweep pass
     uint32_t chain; uint64_t seed; double k1, k2;
+    int dbg_stop;         // diagnostics only: skip everything after stage k (0 = run everything)
 };
+
+// Lanes of ONE wave exchange data through LDS: DS instructions of a wave execute in order, so a compiler-level fence is all
+// that is needed between a phase that writes and a phase that reads.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename real> __device__ __forceinline__ real row_normal(uint32_t wa, uint32_t wb)
+{
+    return r_sqrt(real(-2) * r_log(word_to_unif<real>(wa))) * r_cos2pi(word_to_unif<real>(wb));
+}
 
 template <typename T> __device__ __forceinline__ T bfly_sum(T v, int lo, int hi)   // sum over lanes differing in bits [lo, hi)
 {
@@ -76,6 +94,7 @@ __device__ __forceinline__ float  log1pexp_r(float x)  { return fmaxf(x, 0.f) + 
 __device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
 constexpr double LOG_2PI = 1.8378770664093454836;
+constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Row pass.  blockDim.x = 64 * nWaves; workgroup b owns a contiguous range of subjects.
@@ -93,7 +112,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
     const int J = A.J, W = A.W, R = 64 / W, IPL = A.IPL;
-    const int p = A.nFeat + 1;                       // [1 X]
+    const int F = A.nFeat, p = F + 1;                // design [1 X]
     const int NG = ST::ng(p);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
     const int s = lane & (W - 1), r = lane >> A.logW;
@@ -101,11 +120,16 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* sh_struct = reinterpret_cast<double*>(smem);        // 8 + 2*PMAX doubles
     double* sh_acc = sh_struct + 8 + 2 * PMAX;                  // [nWaves][NSTAT][J]
-    double* sh_gacc = sh_acc + (size_t)nWaves * NSTAT * J;      // [nWaves][NG][R]
-    double* sh_ll = sh_gacc + (size_t)nWaves * NG * R;          // [nWaves]
-    real* sh_item = reinterpret_cast<real*>(sh_ll + nWaves);    // [NITEMARR][J]
+    double* sh_gacc = sh_acc + (size_t)nWaves * NSTAT * J;      // [nWaves][NG]
+    real* sh_item = reinterpret_cast<real*>(sh_gacc + (size_t)nWaves * NG);    // [NITEMARR][J]
     real* sh_a = sh_item, *sh_b = sh_item + J, *sh_a2 = sh_item + 2 * J, *sh_a2b = sh_item + 3 * J;
     real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
+    real* sh_th = sh_item + NITEMARR * J + (size_t)wave * 4 * A.rows_per_wave;   // theta_t of this wave's subjects
+    real* sh_rs = sh_th + A.rows_per_wave;                                         // [rows_per_wave][3] row sums
+
+    const uint8_t* __restrict__ gY = A.Y;
+    const real* __restrict__ gC = A.C;
+    const real* __restrict__ gX = A.X;
 
     const uint32_t sweep = A.ctl->sweep;
     const uint32_t trow = A.ctl->row;
@@ -121,10 +145,10 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         double v = 0.0;
         if (threadIdx.x < 4) v = A.par[par_off_sigp(J) + threadIdx.x];
         else if (threadIdx.x >= 8) v = A.par[par_off_beta(J) + threadIdx.x - 8];
-        else if (threadIdx.x == 4) { double t = 0.0; for (int j = 0; j < J; ++j) t += 1.0 / A.par[3 * J + j]; v = t; }   // sum_j 1/sig2t_j
+        else if (threadIdx.x == 4) v = A.par[par_off_derived(J)];                // sum_j 1/sig2t_j
         sh_struct[threadIdx.x] = v;
     }
-    for (int e = threadIdx.x; e < nWaves * (NSTAT * J + NG * R + 1); e += blockDim.x) sh_acc[e] = 0.0;
+    for (int e = threadIdx.x; e < nWaves * NG; e += blockDim.x) sh_gacc[e] = 0.0;
     __syncthreads();
 
     const real sig11 = (MODEL == MLIRT) ? real(1) : (real)sh_struct[0];
@@ -132,106 +156,120 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     const real sum_isig = (real)sh_struct[4];
     const double* beta = sh_struct + 8;
     const real k1 = (real)A.k1, k2 = (real)A.k2;
+    // bivariate-normal log-density constants of Sigma_p (src/GibbsRtIrt.pl.jl:268-269)
+    const double sp_det = sh_struct[0] * sh_struct[3] - sh_struct[1] * sh_struct[2];
+    const double sp_c0 = -LOG_2PI - 0.5 * log(sp_det);
+    const double sp_q00 = sh_struct[3] / sp_det, sp_q01 = -(sh_struct[1] + sh_struct[2]) / sp_det, sp_q11 = sh_struct[0] / sp_det;
     double* acc = sh_acc + (size_t)wave * NSTAT * J;
-    double* gacc = sh_gacc + (size_t)wave * NG * R;
+    double* gtot = sh_gacc + (size_t)wave * NG;
     double ll = 0.0;
 
     const long long row0 = (long long)blockIdx.x * A.rows_per_block;
     const long long row1 = (row0 + A.rows_per_block < A.N) ? row0 + A.rows_per_block : A.N;
+    // wave w owns a contiguous, balanced slice [ra, rb) of the workgroup's subjects
+    const int nrows_blk = (int)(row1 - row0);
+    const int rbase = nrows_blk / nWaves, rrem = nrows_blk % nWaves;
+    const long long ra = row0 + (long long)wave * rbase + (wave < rrem ? wave : rrem);
+    const long long rb = ra + rbase + (wave < rrem ? 1 : 0);
+    if (A.dbg_stop == 1) return;
 
-    // =================================================================================================== phase 1
-    for (long long g0 = row0 + (long long)wave * R; g0 < row1; g0 += (long long)nWaves * R) {
-        const long long i = g0 + r;
-        const bool rowok = i < row1;
-        const size_t base = (size_t)(rowok ? i : row0) * J;
-
-        // ---------------- sums over the subject's items
-        real sA = 0, sB = 0, sC = 0, sD = 0;
-        real th = rowok ? A.theta[i] : real(0);
-        real ze = (MODEL != MLIRT && rowok) ? A.zeta[i] : real(0);
-        if (PHASE == 0) {
-            if (rowok && A.mode == 1) for (int k = 0; k < IPL; ++k) {
-                const int j = s + W * k;
-                if (j < J) {
-                    const real w = A.omega[base + j];
-                    const real kap = (real)A.Y[base + j] - real(0.5);
-                    sA += sh_a2[j] * w;
-                    sB += sh_a[j] * kap + sh_a2b[j] * w;
-                    if (MODEL == RTIRT || MODEL == LATENTQR) sC += (sh_lamc[j] - A.C[base + j]) * sh_isig[j];
+    // =================================================================================================== phase 1 (i)
+    // sums over each subject's items; lane (r, s): subject r of the group, items s, s+W, ...
+    if (A.mode == 1) {
+        for (long long g0 = ra; g0 < rb; g0 += R) {
+            const long long i = g0 + r;
+            const bool rowok = i < rb;
+            const size_t base = (size_t)(rowok ? i : ra) * J;
+            real s0 = 0, s1 = 0, s2 = 0;
+            // batches of 4 items per lane with every load issued before any use (clamped index + mask: no branches)
+            const real thr = (PHASE == 1 && rowok) ? A.theta[i] : real(0);
+            for (int k0 = 0; k0 < IPL; k0 += KB) {
+                real wv[KB], cv[KB], yv[KB]; int jv4[KB]; bool ok4[KB];
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int j = s + W * (k0 + u);
+                    ok4[u] = rowok && (k0 + u) < IPL && j < J;
+                    jv4[u] = ok4[u] ? j : 0;
+                    const size_t e = base + jv4[u];
+                    wv[u] = (PHASE == 0) ? A.omega[e] : A.nu[e];
+                    yv[u] = (PHASE == 0) ? (real)gY[e] : real(0);
+                    cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
+                }
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int j = jv4[u];
+                    const real m = ok4[u] ? real(1) : real(0);
+                    if (PHASE == 0) {
+                        const real kap = yv[u] - real(0.5);
+                        s0 += m * (sh_a2[j] * wv[u]);
+                        s1 += m * (sh_a[j] * kap + sh_a2b[j] * wv[u]);
+                        if (MODEL == RTIRT || MODEL == LATENTQR) s2 += m * ((sh_lamc[j] - cv[u]) * sh_isig[j]);
+                    } else {   // CrossQr pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202)
+                        const real nu = ok4[u] ? wv[u] : real(1);
+                        const real iden = r_div(sh_isig[j], k2 * nu);
+                        s0 += m * iden;
+                        s2 += m * ((sh_lamc[j] - cv[u] - thr * sh_rho[j] + k1 * nu) * iden);
+                    }
                 }
             }
-            sA = bfly_sum(sA, 1, W); sB = bfly_sum(sB, 1, W);
-            if (MODEL == RTIRT || MODEL == LATENTQR) sC = bfly_sum(sC, 1, W);
-        } else {   // CrossQr pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202)
-            if (rowok && A.mode == 1) for (int k = 0; k < IPL; ++k) {
-                const int j = s + W * k;
-                if (j < J) {
-                    const real nu = A.nu[base + j];
-                    const real iden = r_div(sh_isig[j], k2 * nu);
-                    sD += iden;
-                    sC += (sh_lamc[j] - A.C[base + j] - th * sh_rho[j] + k1 * nu) * iden;
-                }
-            }
-            sC = bfly_sum(sC, 1, W); sD = bfly_sum(sD, 1, W);
+            s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W);
+            if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
+            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - ra); o[0] = s0; o[1] = s1; o[2] = s2; }
         }
+    }
+    wave_sync();
+    if (A.dbg_stop == 5) return;
 
-        // ---------------- row draws (computed redundantly by the W lanes of the row)
-        real nu_row = real(1), xb5 = real(0), mu0a = real(0), mu0b = real(0);
-        if (rowok && PHASE == 0 && MODEL != CROSSQR) {
-            // x_i' beta for the columns this model needs ([1 X] design; LatentQr adds theta below)
+    // =================================================================================================== phase 1 (ii)
+    // one lane per subject: theta_t / zeta_t draws, per-subject outputs, structural log-likelihood, LatentQr's nu_{t+1}
+    for (long long ib = ra; ib < rb; ib += 64) {
+        const bool rok = ib + lane < rb;
+        const long long i = rok ? ib + lane : ra;          // clamped: loads are unconditional, stores masked
+        const int li = (int)(i - ra);
+        real th = A.theta[i];
+        real ze = (MODEL != MLIRT) ? A.zeta[i] : real(0);
+        real nu_row = real(1);
+        if (MODEL == LATENTQR) nu_row = A.nu[i];
+        real mu0a = 0, mu0b = 0;
+        if (PHASE == 0 && MODEL != CROSSQR) {
             for (int u = 0; u < p; ++u) {
-                const real xu = (u == 0) ? real(1) : A.X[(size_t)i * A.nFeat + (u - 1)];
+                const real xu = (u == 0) ? real(1) : gX[(size_t)i * F + (u - 1)];
                 mu0a += xu * (real)beta[u];
                 if (MODEL == RTIRT) mu0b += xu * (real)beta[PMAX + u];
             }
         }
-        if (A.mode == 1 && rowok) {
+        real xb5 = 0, nu_next = real(0);
+        if (A.mode == 1) {
+            const real sA = sh_rs[3 * li], sB = sh_rs[3 * li + 1], sC = sh_rs[3 * li + 2];
+            // one Philox block per subject and sweep feeds both row draws: words 0,1 -> theta's normal, words 2,3 -> zeta's
+            uint32_t rw0, rw1, rw2, rw3;
+            philox4x32_10((uint32_t)i, 0u, sweep, ((uint32_t)SITE_THETA << 24) | ((A.chain & 0xFFu) << 16), (uint32_t)A.seed, (uint32_t)(A.seed >> 32), rw0, rw1, rw2, rw3);
             if (PHASE == 0) {
                 // theta: src/Draw.pl.jl:49-62 (prior x*beta[:,1]) / :67-80 (Null prior)
                 const real mu0 = (MODEL == MLIRT || MODEL == RTIRT) ? mu0a : real(0);
                 const real parV = r_rcp(r_rcp(sig11) + sA);
                 const real parM = parV * (r_div(mu0, sig11) + sB);
-                Stream st(A.seed, A.chain, SITE_THETA, (uint32_t)i, 0u, sweep);
-                th = parM + r_sqrt(parV) * normal<real>(st);
+                th = parM + r_sqrt(parV) * row_normal<real>(rw0, rw1);
             }
             if (MODEL == RTIRT || MODEL == LATENTQR) {
                 // zeta: src/Draw.pl.jl:132-141 / :161-174
                 real mu0 = mu0b, s0 = sig22;
                 if (MODEL == LATENTQR) {
-                    nu_row = A.nu[i];
                     xb5 = mu0a + th * (real)beta[p];
                     mu0 = xb5 + k1 * nu_row;
                     s0 = sig22 * (k2 * nu_row);
                 }
                 const real parV = r_rcp(r_rcp(s0) + sum_isig);
                 const real parM = parV * (r_div(mu0, s0) + sC);
-                Stream st(A.seed, A.chain, SITE_ZETA, (uint32_t)i, 0u, sweep);
-                ze = parM + r_sqrt(parV) * normal<real>(st);
+                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
             }
             if (MODEL == CROSSQR && PHASE == 1) {
-                // zeta: src/Draw.pl.jl:192-206 (zero prior mean, prior variance Sigp[2,2])
-                const real parV = r_rcp(r_rcp(sig22) + sD);
+                // zeta: src/Draw.pl.jl:192-206 (zero prior mean, prior variance Sigp[2,2]); sA = sum of weights here
+                const real parV = r_rcp(r_rcp(sig22) + sA);
                 const real parM = parV * sC;
-                Stream st(A.seed, A.chain, SITE_ZETA, (uint32_t)i, 0u, sweep);
-                ze = parM + r_sqrt(parV) * normal<real>(st);
+                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
             }
-        } else if (MODEL == LATENTQR && rowok) {
-            nu_row = A.nu[i];
-            xb5 = mu0a + th * (real)beta[p];
-        }
-
-        // ---------------- per-subject outputs, structural log-likelihood, next-sweep nu (LatentQr), global statistics
-        real nu_next = real(1);
-        if (MODEL == LATENTQR && rowok) {
-            // nu_{t+1}: src/Draw.pl.jl:325-343 (depends on zeta_t, theta_t, beta_t, Sigp_t only)
-            const real den = r_sqrt(sig22 * k2);
-            const real parA = r_div(r_abs(ze - xb5), den);
-            const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
-            Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, 0u, sweep + 1u);
-            nu_next = qr_weight<real>(st, parA, parB);
-        }
-        if (rowok && s == 0) {
-            if (A.mode == 1) {
+            if (rok) {
                 if (PHASE == 0) {
                     A.theta[i] = th;
                     if (A.tr_theta) A.tr_theta[(size_t)trow * A.N + i] = th;
@@ -247,11 +285,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     const real e = th - mu0a;
                     ll += -0.5 * LOG_2PI - 0.5 * (double)(e * e);
                 } else if (MODEL == RTIRT || (MODEL == CROSSQR && PHASE == 1)) {
-                    const double s00 = sh_struct[0], s10 = sh_struct[1], s01 = sh_struct[2], s11 = sh_struct[3];
-                    const double det = s00 * s11 - s10 * s01;
                     const double e0 = (double)(th - mu0a), e1 = (double)(ze - mu0b);
-                    const double q = (s11 * e0 * e0 - (s10 + s01) * e0 * e1 + s00 * e1 * e1) / det;
-                    ll += -LOG_2PI - 0.5 * log(det) - 0.5 * q;
+                    ll += sp_c0 - 0.5 * (sp_q00 * e0 * e0 + sp_q01 * e0 * e1 + sp_q11 * e1 * e1);
                 } else if (MODEL == LATENTQR) {
                     const double var = (double)sig22 * ((double)k2 * (double)nu_row);
                     const double e = (double)(ze - (xb5 + k1 * nu_row));
@@ -260,66 +295,100 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     if (post_burn) A.sum_nu[i] += (double)nu_row;
                 }
             }
-            if (MODEL == LATENTQR) A.nu[i] = nu_next;
-            // global statistics for the next tiny step (lane-private LDS slots: gacc[g][r])
-            if (PHASE == 0 && MODEL != CROSSQR) {
-                int o = 0;
-                for (int u = 0; u < p; ++u) {
-                    const double xu = (u == 0) ? 1.0 : (double)A.X[(size_t)i * A.nFeat + (u - 1)];
-                    gacc[u * R + r] += xu * (double)th;
-                    if (MODEL == RTIRT) gacc[(p + u) * R + r] += xu * (double)ze;
-                    if (MODEL == LATENTQR) gacc[(p + 1 + u) * R + r] += xu * ((double)ze - (double)k1 * (double)nu_next);
-                }
-                o = p;
-                if (MODEL == RTIRT) {
-                    o += p;
-                    gacc[(o + 0) * R + r] += (double)th * (double)th;
-                    gacc[(o + 1) * R + r] += (double)th * (double)ze;
-                    gacc[(o + 2) * R + r] += (double)ze * (double)ze;
-                } else if (MODEL == LATENTQR) {
-                    const double uu = (double)ze - (double)k1 * (double)nu_next;
-                    gacc[(o + 0) * R + r] += (double)th * (double)th; o += 1 + p;
-                    gacc[(o + 0) * R + r] += (double)th * uu;
-                    gacc[(o + 1) * R + r] += uu * uu;
-                    gacc[(o + 2) * R + r] += (double)nu_next;
-                    gacc[(o + 3) * R + r] += (double)nu_next * (double)nu_next;
-                    gacc[(o + 4) * R + r] += (double)ze;
-                    gacc[(o + 5) * R + r] += (double)ze * (double)ze;
-                }
-            }
-            if (MODEL == CROSSQR && PHASE == 1) gacc[0 * R + r] += (double)ze * (double)ze;
+        } else if (MODEL == LATENTQR) {
+            xb5 = mu0a + th * (real)beta[p];
         }
+        if (MODEL == LATENTQR) {
+            // nu_{t+1}: src/Draw.pl.jl:325-343 (depends on zeta_t, theta_t, beta_t, Sigp_t only)
+            const real den = r_sqrt(sig22 * k2);
+            const real parA = r_div(r_abs(ze - xb5), den);
+            const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
+            Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, 0u, sweep + 1u);
+            nu_next = qr_weight<real>(st, parA, parB);
+            if (rok) A.nu[i] = nu_next;
+        }
+        if (PHASE == 0 && rok) sh_th[li] = th;
 
-        // ---------------- omega_{t+1} | theta_t, a_t, b_t  (src/Draw.pl.jl:36-40), persistent lanes:
-        // every lane walks through its own IPL cells, one single-block PG attempt per trip, and moves on to its next cell as
-        // soon as a draw is accepted, so a wave pays the max over lanes of the TOTAL attempts rather than the sum over cells of
-        // the max.  Attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
-        if constexpr (PHASE == 0) {
-            int j = s;
-            bool active = rowok && j < J;
-            uint32_t att = 0;
-            real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
-            const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
-            while (__any(active)) {
-                if (active) {
-                    uint32_t w0, w1, w2, w3;
-                    philox4x32_10((uint32_t)i, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
-                    real w;
-                    const bool acc_ = pg1_attempt<real>(z, w0, w1, w2, w3, w);
-                    if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
-                        A.omega[base + j] = w;
-                        j += W; att = 0;
-                        active = j < J;
-                        if (active) z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j]));
-                    } else ++att;
-                }
+        // ---- global statistics for the next tiny step: each is a sum over subjects of a product of two per-subject values;
+        // summed over the 64 subjects of this trip by a wave butterfly (fixed order), then accumulated by lane 0.
+        // value codes: 0 -> 1, 1..F -> X columns, F+1 theta, F+2 zeta, F+3 u = zeta - k1 nu_{t+1}, F+4 nu_{t+1}
+        if (NG > 1) {
+            const int cT = F + 1, cZ = F + 2, cU = F + 3, cN = F + 4;
+            const double thd = (double)th, zed = (double)ze, nud = (double)nu_next, upd = zed - (double)k1 * nud;
+            auto val = [&](int code) -> double {
+                if (code == 0) return 1.0;
+                if (code <= F) return (double)gX[(size_t)i * F + (code - 1)];
+                if (code == cT) return thd;
+                if (code == cZ) return zed;
+                if (code == cU) return upd;
+                return nud;
+            };
+            for (int g = 0; g < NG - 1; ++g) {
+                int ca = 0, cb2 = 0;
+                if (MODEL == MLIRT) { ca = g; cb2 = cT; }
+                else if (MODEL == RTIRT) {
+                    if (g < p) { ca = g; cb2 = cT; }
+                    else if (g < 2 * p) { ca = g - p; cb2 = cZ; }
+                    else if (g == 2 * p) { ca = cT; cb2 = cT; }
+                    else if (g == 2 * p + 1) { ca = cT; cb2 = cZ; }
+                    else { ca = cZ; cb2 = cZ; }
+                } else if (MODEL == LATENTQR) {
+                    if (g < p) { ca = g; cb2 = cT; }
+                    else if (g == p) { ca = cT; cb2 = cT; }
+                    else if (g < 2 * p + 1) { ca = g - p - 1; cb2 = cU; }
+                    else if (g == 2 * p + 1) { ca = cT; cb2 = cU; }
+                    else if (g == 2 * p + 2) { ca = cU; cb2 = cU; }
+                    else if (g == 2 * p + 3) { ca = 0; cb2 = cN; }
+                    else if (g == 2 * p + 4) { ca = cN; cb2 = cN; }
+                    else if (g == 2 * p + 5) { ca = 0; cb2 = cZ; }
+                    else { ca = cZ; cb2 = cZ; }
+                } else { ca = cZ; cb2 = cZ; }      // CrossQr pass B: sum zeta^2
+                double v = rok ? val(ca) * val(cb2) : 0.0;
+                v = bfly_sum(v, 1, 64);
+                if (lane == 0) gtot[g] += v;
             }
         }
     }
+    if (A.dbg_stop == 2) return;
+
+    // ---------------- omega_{t+1} | theta_t, a_t, b_t  (src/Draw.pl.jl:36-40), persistent lanes over the wave's flattened cells:
+    // lane l owns cells l, l+64, l+128, ... of the slice (cell c = (subject ra + c / J, item c % J), which is also its offset in
+    // the row-major omega slice, so stores are fully coalesced).  Each trip makes ONE single-block PG attempt; a lane moves on
+    // to its next cell as soon as a draw is accepted, so a wave pays the max over lanes of the TOTAL attempts of ~equal queues.
+    // Attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
+    if constexpr (PHASE == 0) {
+        wave_sync();                                  // sh_th written above
+        const int ncell = (int)(rb - ra) * J;
+        const int qJ = 64 / J, rJ = 64 % J;
+        int c = lane, rr = lane / J, j = lane % J;
+        bool active = c < ncell;
+        uint32_t att = 0;
+        real th = active ? sh_th[rr] : real(0);
+        real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
+        real* om = A.omega + (size_t)ra * J;
+        const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
+        while (__any(active)) {
+            if (active) {
+                uint32_t w0, w1, w2, w3;
+                philox4x32_10((uint32_t)(ra + rr), (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                real w;
+                const bool acc_ = pg1_attempt<real>(z, w0, w1, w2, w3, w);
+                if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
+                    om[c] = w;
+                    c += 64; rr += qJ; j += rJ; att = 0;
+                    if (j >= J) { j -= J; ++rr; }
+                    active = c < ncell;
+                    if (active) { th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
+                } else ++att;
+            }
+        }
+    }
+    if (A.dbg_stop == 3) return;
     __syncthreads();
 
     // =================================================================================================== phase 2
-    for (int cb = 0; cb * 64 < J; ++cb) {
+    // lane = item j; the waves stride over the workgroup's subjects; accumulators live in fp64 registers
+    for (int cb = 0; cb * 64 < J && A.dbg_stop != 7; ++cb) {
         const int j = cb * 64 + lane;
         const bool jv = j < J;
         const real a = jv ? sh_a[j] : real(0), b = jv ? sh_b[j] : real(0);
@@ -329,17 +398,32 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
 #pragma unroll
         for (int q = 0; q < NSTAT; ++q) S[q] = 0.0;
         double llc = 0.0;
-#pragma unroll 2
-        for (long long i = row0 + wave; i < row1; i += nWaves) {
-            const real th = A.theta[i];
-            const real ze = (MODEL != MLIRT) ? A.zeta[i] : real(0);
-            if (jv) {
+        const int jc = jv ? j : 0;
+        for (long long i0 = row0 + wave; i0 < row1; i0 += 4LL * nWaves) {
+            real thv[4], zev[4], wv[4], cv[4], nv[4]; bool yv[4], okv[4]; long long iv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                 // every load of the batch is issued before any use
+                const long long i = i0 + (long long)u * nWaves;
+                okv[u] = jv && i < row1;
+                iv[u] = i < row1 ? i : row1 - 1;
+                const size_t e = (size_t)iv[u] * J + jc;
+                thv[u] = A.theta[iv[u]];
+                zev[u] = (MODEL != MLIRT) ? A.zeta[iv[u]] : real(0);
+                wv[u] = (PHASE == 0) ? A.omega[e] : real(0);
+                yv[u] = (PHASE == 0) ? (gY[e] != 0) : false;
+                cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
+                nv[u] = (MODEL == CROSSQR) ? A.nu[e] : real(1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!okv[u]) continue;
+                const long long i = iv[u];
                 const size_t e = (size_t)i * J + j;
+                const real th = thv[u], ze = zev[u];
                 if constexpr (PHASE == 0) {
-                    const real w = A.omega[e];
-                    const bool y = A.Y[e] != 0;
-                    real c = 0;
-                    if (MODEL != MLIRT) c = A.C[e];
+                    const real w = wv[u];
+                    const bool y = yv[u];
+                    const real c = cv[u];
                     const double wd = (double)w, thd = (double)th;
                     S[0] += wd; S[1] += wd * thd; S[2] += wd * thd * thd; S[3] += y ? 0.5 * thd : -0.5 * thd;
                     if constexpr (MODEL == RTIRT || MODEL == LATENTQR) S[4] += (double)c * (double)ze;
@@ -354,15 +438,15 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     }
                     if constexpr (MODEL == CROSSQR) {
                         // statistics for lambda_t, sig2t_t (src/Draw.pl.jl:246-247, 285) with nu_t, zeta_{t-1}, theta_t, rho_t
-                        const real nu = A.nu[e];
+                        const real nu = nv[u];
                         const real rr = c + ze + th * rho - k1 * nu;
                         const double inu = 1.0 / (double)nu, rd = (double)rr;
                         S[4] += inu; S[5] += rd * inu; S[6] += rd * rd * inu; S[7] += (double)nu;
                     }
                 } else {
                     // CrossQr pass B: RT log-likelihood with nu_t, then nu_{t+1} (src/Draw.pl.jl:303-320) and rho statistics (:484-485)
-                    const real c = A.C[e];
-                    const real nu = A.nu[e];
+                    const real c = cv[u];
+                    const real nu = nv[u];
                     if (A.mode == 1) {
                         const real var_ = k2 * nu;                               // times sig2t_j
                         const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
@@ -388,23 +472,18 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         ll += llc;
     }
 
+    if (A.dbg_stop == 4) return;
+
     // ---------------- block epilogue: fixed-order reduction of the wave accumulators into this block's slab row
     ll = bfly_sum(ll, 1, 64);
-    if (lane == 0) sh_ll[wave] = ll;
+    if (lane == 0) sh_gacc[(size_t)wave * NG + NG - 1] = ll;
     __syncthreads();
     const int NS = NSTAT * J + NG;
     double* out = A.slab + (size_t)blockIdx.x * NS;
     for (int e = threadIdx.x; e < NS; e += blockDim.x) {
         double t = 0.0;
-        if (e < NSTAT * J) {
-            for (int w = 0; w < nWaves; ++w) t += sh_acc[(size_t)w * NSTAT * J + e];
-        } else if (e < NS - 1) {
-            const int gi = e - NSTAT * J;
-            for (int w = 0; w < nWaves; ++w)
-                for (int rr = 0; rr < R; ++rr) t += sh_gacc[(size_t)w * NG * R + gi * R + rr];
-        } else {
-            for (int w = 0; w < nWaves; ++w) t += sh_ll[w];
-        }
+        if (e < NSTAT * J) { for (int w = 0; w < nWaves; ++w) t += sh_acc[(size_t)w * NSTAT * J + e]; }
+        else { const int gi = e - NSTAT * J; for (int w = 0; w < nWaves; ++w) t += sh_gacc[(size_t)w * NG + gi]; }
         out[e] = t;
     }
 }
@@ -422,6 +501,7 @@ struct TinyArgs {
     int intercept, onepl, cov2one, sigp_mode;
     uint32_t chain; uint64_t seed; double k1, k2;
     int nq;               // number of small qr entries recorded per sweep
+    int dbg_stop;         // diagnostics only: return after stage k (0 = run everything)
 };
 
 __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
@@ -433,17 +513,8 @@ __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
     S[0] = 1.0; S[3] = 1.0;
 }
 
-// Lanes of ONE wave exchange data through LDS: DS instructions of a wave execute in order, so a compiler-level fence is all
-// that is needed between a phase that writes and a phase that reads.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 constexpr int TINY_THREADS = 1024;
-constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX;   // LDS scratch doubles for the structural wave
+constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX + 8;   // LDS scratch doubles for the structural wave
 
 // STEP: 0 = the per-sweep step of single-pass models / CrossQr step 1; 1 = CrossQr step 2 (lambda, sig2t)
 template <int MODEL, int STEP>
@@ -463,19 +534,25 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     double* st1 = st0 + NS0;                                // NS1 reduced statistics of slab1
     double* part = st1 + NS1;                               // 4 * max(NS0, NS1) partial sums
     double* work = part + 4 * (NS0 > NS1 ? NS0 : NS1);      // TINY_WORK scratch
+    double* sh_x = work + TINY_WORK;                        // x'x and its inverse (2 * PMAX * PMAX), staged once
     const int tid = threadIdx.x;
+    if (tid < 2 * PMAX * PMAX) sh_x[tid] = T.cst[cst_off_xtx(T.J) + tid];
 
     // ---- fixed-order slab reduction: 4 chains per statistic, each with 8 independent partial sums (loads in flight)
     auto reduce = [&](const double* slab, int nb, int NS, double* out) {
         const int part_id = tid >> 8, e0 = tid & 255;
         for (int e = e0; e < NS; e += 256) {
-            double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int b = part_id;
-            for (; b + 28 < nb; b += 32) {
+            double t[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] += slab[(size_t)(b + 4 * u) * NS + e];
+            for (int u = 0; u < 16; ++u) t[u] = 0.0;
+            int b = part_id;
+            for (; b + 60 < nb; b += 64) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] += slab[(size_t)(b + 4 * u) * NS + e];
             }
             for (; b < nb; b += 4) t[0] += slab[(size_t)b * NS + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] += t[u + 8];
             part[part_id * NS + e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         }
         __syncthreads();
@@ -496,19 +573,37 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
         T.tr_ll[prev_row] = llv;
     }
     if (T.mode == 1) return;
+    if (T.dbg_stop == 1) return;
 
     const double* K0 = T.cst + cst_off_k0(J);
     const double* cm = T.cst + cst_off_m(J);
     const double* csq = T.cst + cst_off_csq(J);
     const double muLam = T.cst[cst_off_mu(J)], sdLam = T.cst[cst_off_mu(J) + 1];
-    const double* XtX = T.cst + cst_off_xtx(J);             // p x p, column-major with leading dimension PMAX
-    const double* Xinv = T.cst + cst_off_xinv(J);           // (x'x)^-1, same layout
+    const double* XtX = sh_x;                               // p x p, column-major with leading dimension PMAX
+    const double* Xinv = sh_x + PMAX * PMAX;                // (x'x)^-1, same layout
     double* par = T.par;
     double* Sigp = par + par_off_sigp(J);
     double* beta = par + par_off_beta(J);
     const double* G0 = st0 + NSTAT0 * J;                    // global statistics of slab0
 
-    // =========================================================== structural draws: wave 0
+    // =========================================================== structural draws
+    // wave 1, lane 0: the random numbers of the Sigma_p draw do not depend on beta_t, so they are drawn concurrently with it:
+    //   RtIrt   : c1^2 ~ chi2(N+3), n21 ~ N(0,1), c2^2 ~ chi2(N+2) (Bartlett factor of the Wishart; same stream order as the oracle)
+    //   others  : g ~ Gamma(shape) of the InverseGamma
+    double* spd = work + TINY_WORK - 4;
+    if (tid == 64 && STEP == 0 && MODEL != MLIRT) {
+        Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
+        if (MODEL == RTIRT) {
+            const double df = Nd + 3.0;
+            spd[0] = sqrt(chisq(ss, df));
+            spd[1] = normal<double>(ss);
+            spd[2] = sqrt(chisq(ss, df - 1.0));
+        } else {
+            spd[0] = gamma_mt(ss, 1e-3 + (MODEL == LATENTQR ? Nd * 3.0 / 2.0 : Nd / 2.0));
+        }
+    }
+    // wave 0: beta_t (lanes cooperate through LDS)
+    double* bn = work + TINY_WORK - 4 - 2 * PMAX;           // beta_t, contiguous [2p] / [p+1]
     if (tid < 64 && STEP == 0) {
         const int lane = tid;
         if (MODEL == MLIRT) {
@@ -523,9 +618,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             // `1/sigma^2 .+ M` adds 1 to EVERY element), so by Sherman-Morrison
             //   parV = Minv - v v'/(1 + 1'v),  Minv = kron(Sigp, (x'x)^-1),  v = Minv 1.
             const int n = 2 * p;
-            double* V = work, *L = V + n * n, *tv = L + n * n, *pm = tv + n, *zv = pm + n, *vv = zv + n, *bn = vv + n, *rs = bn + n;
+            double* V = work, *L = V + n * n, *tv = L + n * n, *vv = tv + n, *rs = vv + n;
             const double* xt = G0, *xz = G0 + p;
-            const double tt = G0[2 * p], tz = G0[2 * p + 1], zz = G0[2 * p + 2];
             const double s00 = Sigp[0], s10 = Sigp[1], s01 = Sigp[2], s11 = Sigp[3];
             const double sdet = s00 * s11 - s10 * s01;
             const double iO[4] = { s11 / sdet, -s10 / sdet, -s01 / sdet, s00 / sdet };
@@ -546,61 +640,37 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
                 V[e] = Sigp[a_ + 2 * b_] * Xinv[u + w * PMAX] - vv[i] * vv[jj] / cden;
             }
             wave_sync();
-            if (lane < n) { double t = 0.0; for (int jj = 0; jj < n; ++jj) t += V[lane + jj * n] * tv[jj]; pm[lane] = t; }
-            if (lane == 0) {
-                // Cholesky (lower) of parV and the 2p standard normals, in stream order
-                for (int jj = 0; jj < n; ++jj) {
-                    double d = V[jj + jj * n];
-                    for (int k = 0; k < jj; ++k) d -= L[jj + k * n] * L[jj + k * n];
-                    d = sqrt(d);
-                    L[jj + jj * n] = d;
-                    for (int i = jj + 1; i < n; ++i) {
-                        double v = V[i + jj * n];
-                        for (int k = 0; k < jj; ++k) v -= L[i + k * n] * L[jj + k * n];
-                        L[i + jj * n] = v / d;
-                    }
+            double pm = 0.0;
+            if (lane < n) for (int jj = 0; jj < n; ++jj) pm += V[lane + jj * n] * tv[jj];
+            // lower Cholesky factor, one column per step, rows in parallel across lanes
+            for (int jj = 0; jj < n; ++jj) {
+                double t = 0.0;
+                if (lane >= jj && lane < n) {
+                    t = V[lane + jj * n];
+                    for (int k = 0; k < jj; ++k) t -= L[lane + k * n] * L[jj + k * n];
                 }
-                Stream sb(T.seed, T.chain, SITE_BETA, 0u, 0u, sweep);
-                for (int i = 0; i < n; ++i) zv[i] = normal<double>(sb);
+                const double d = sqrt(__shfl(t, jj, 64));
+                if (lane >= jj && lane < n) L[lane + jj * n] = (lane == jj) ? d : t / d;
+                wave_sync();
             }
-            wave_sync();
+            // z_i = i-th normal of stream (BETA, 0, 0, sweep): words 2i, 2i+1, i.e. block i/2 -- drawn by lane i
+            double zi = 0.0;
             if (lane < n) {
-                double t = pm[lane];
-                for (int jj = 0; jj <= lane; ++jj) t += L[lane + jj * n] * zv[jj];
+                uint32_t w0, w1, w2, w3;
+                philox4x32_10(0u, 0u, sweep, ((uint32_t)SITE_BETA << 24) | ((T.chain & 0xFFu) << 16) | (uint32_t)(lane >> 1),
+                              (uint32_t)T.seed, (uint32_t)(T.seed >> 32), w0, w1, w2, w3);
+                const double u1 = word_to_unif<double>((lane & 1) ? w2 : w0), u2 = word_to_unif<double>((lane & 1) ? w3 : w1);
+                zi = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+            }
+            double t = pm;
+            for (int jj = 0; jj < n; ++jj) {
+                const double zj = __shfl(zi, jj, 64);
+                if (lane < n && jj <= lane) t += L[lane + jj * n] * zj;
+            }
+            if (lane < n) {
                 if (!T.intercept && (lane == 0 || lane == p)) t = 0.0;          // src/GibbsRtIrt.pl.jl:293-295
                 bn[lane] = t;
                 beta[(lane / p) * PMAX + (lane % p)] = t;
-            }
-            wave_sync();
-            if (lane == 0) {
-                // drawSubjCovariance src/Draw.pl.jl:499-515 : InverseWishart(N+3, e'e + I), e'e from sufficient statistics
-                double bAb[4] = {0, 0, 0, 0}, bx[4];
-                for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) {
-                    double t = 0.0;
-                    for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) t += bn[a_ * p + u] * XtX[u + v * PMAX] * bn[b_ * p + v];
-                    bAb[a_ + 2 * b_] = t;
-                    double t2 = 0.0; const double* xe = b_ == 0 ? xt : xz;
-                    for (int u = 0; u < p; ++u) t2 += bn[a_ * p + u] * xe[u];
-                    bx[a_ + 2 * b_] = t2;
-                }
-                const double ee00 = tt - 2.0 * bx[0] + bAb[0];
-                const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
-                const double ee11 = zz - 2.0 * bx[3] + bAb[3];
-                const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
-                const double pdet = Psi[0] * Psi[3] - Psi[1] * Psi[2];
-                const double Pi[4] = { Psi[3] / pdet, -Psi[1] / pdet, -Psi[2] / pdet, Psi[0] / pdet };
-                const double l00 = sqrt(Pi[0]), l10 = Pi[1] / l00, l11 = sqrt(Pi[3] - l10 * l10);
-                const double df = Nd + 3.0;
-                Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
-                const double c1 = sqrt(chisq(ss, df));
-                const double n21 = normal<double>(ss);
-                const double c2 = sqrt(chisq(ss, df - 1.0));
-                const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
-                const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
-                const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
-                double S[4] = { Wm[3] / det, -Wm[1] / det, -Wm[2] / det, Wm[0] / det };
-                if (T.cov2one) d_cov2one(S);
-                for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
             }
         } else if (MODEL == LATENTQR) {
             // getSubjCoefficientsLatentQr src/Draw.pl.jl:446-458 : beta = (x'x)^-1 x'(zeta - k1 nu), x = [1 X theta];
@@ -608,8 +678,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             if (lane == 0) {
                 const int q = p + 1;
                 const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
-                const double tu = G0[2 * p + 1], uu = G0[2 * p + 2], snu = G0[2 * p + 3], snu2 = G0[2 * p + 4];
-                double* h = work, *g = h + PMAX, *bn = g + PMAX;
+                const double tu = G0[2 * p + 1];
+                double* h = work, *g = h + PMAX;
                 double hx = 0.0, hu = 0.0;
                 for (int u = 0; u < p; ++u) {
                     double t1 = 0.0, t2 = 0.0;
@@ -622,36 +692,13 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
                 bn[p] = b2;
                 if (!T.intercept) bn[0] = 0.0;                                   // src/GibbsRtIrtLatent.pl.jl:288-290
                 for (int u = 0; u < q; ++u) beta[u] = bn[u];
-                // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
-                double sr2 = uu;
-                for (int u = 0; u < p; ++u) sr2 -= 2.0 * bn[u] * xu[u];
-                sr2 -= 2.0 * bn[p] * tu;
-                for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
-                for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
-                sr2 += bn[p] * bn[p] * tt;
-                const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
-                const double parB = 1e-3 + sr2 * sw / sw2 + snu;
-                Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
-                const double v = invgamma(ss, 1e-3 + Nd * 3.0 / 2.0, parB);
-                double S[4] = { 1.0, 0.0, 0.0, v };
-                if (T.cov2one) d_cov2one(S);
-                for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
-            }
-        } else if (MODEL == CROSSQR) {
-            if (lane == 0) {
-                // drawSubjCovarianceCross src/Draw.pl.jl:542-557
-                const double zz = st1[NSTAT1 * J + 0];
-                Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
-                const double v = invgamma(ss, 1e-3 + Nd / 2.0, 1e-3 + zz / 2.0);
-                double S[4] = { 1.0, 0.0, 0.0, v };
-                if (T.cov2one) d_cov2one(S);
-                for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
             }
         }
     }
 
-    // =========================================================== item draws: one thread per item, in waves 1..
-    const int j = tid - 64;
+    if (T.dbg_stop == 2) return;
+    // =========================================================== item draws: one thread per item, in waves 2..
+    const int j = tid - 128;
     if (j >= 0 && j < J) {
         if (STEP == 0) {
             const double S0 = st0[0 * J + j], S1 = st0[1 * J + j], S2 = st0[2 * J + j], K1 = st0[3 * J + j];
@@ -717,6 +764,61 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     }
     __syncthreads();
 
+    if (T.dbg_stop == 3) return;
+    // derived scalar for the row pass: sum_j 1/sig2t_j (fixed order)
+    if (tid == 64) { double t = 0.0; for (int jj = 0; jj < J; ++jj) t += 1.0 / par[3 * J + jj]; par[par_off_derived(J)] = t; }
+    // =========================================================== Sigma_p_t | beta_t (thread 0; its random numbers were pre-drawn above)
+    if (tid == 0 && STEP == 0 && MODEL != MLIRT) {
+        double S[4] = { 1.0, 0.0, 0.0, 1.0 };
+        if (MODEL == RTIRT) {
+            // drawSubjCovariance src/Draw.pl.jl:499-515 : InverseWishart(N+3, e'e + I), e'e from sufficient statistics
+            const double* xt = G0, *xz = G0 + p;
+            const double tt = G0[2 * p], tz = G0[2 * p + 1], zz = G0[2 * p + 2];
+            double bAb[4] = {0, 0, 0, 0}, bx[4];
+            for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) {
+                double t = 0.0;
+                for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) t += bn[a_ * p + u] * XtX[u + v * PMAX] * bn[b_ * p + v];
+                bAb[a_ + 2 * b_] = t;
+                double t2 = 0.0; const double* xe = b_ == 0 ? xt : xz;
+                for (int u = 0; u < p; ++u) t2 += bn[a_ * p + u] * xe[u];
+                bx[a_ + 2 * b_] = t2;
+            }
+            const double ee00 = tt - 2.0 * bx[0] + bAb[0];
+            const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
+            const double ee11 = zz - 2.0 * bx[3] + bAb[3];
+            const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
+            const double pdet = Psi[0] * Psi[3] - Psi[1] * Psi[2];
+            const double Pi[4] = { Psi[3] / pdet, -Psi[1] / pdet, -Psi[2] / pdet, Psi[0] / pdet };
+            const double l00 = sqrt(Pi[0]), l10 = Pi[1] / l00, l11 = sqrt(Pi[3] - l10 * l10);
+            const double c1 = spd[0], n21 = spd[1], c2 = spd[2];
+            const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
+            const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
+            const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
+            S[0] = Wm[3] / det; S[1] = -Wm[1] / det; S[2] = -Wm[2] / det; S[3] = Wm[0] / det;
+        } else if (MODEL == LATENTQR) {
+            // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
+            const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
+            const double tu = G0[2 * p + 1], uu = G0[2 * p + 2], snu = G0[2 * p + 3], snu2 = G0[2 * p + 4];
+            double sr2 = uu;
+            for (int u = 0; u < p; ++u) sr2 -= 2.0 * bn[u] * xu[u];
+            sr2 -= 2.0 * bn[p] * tu;
+            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
+            for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
+            sr2 += bn[p] * bn[p] * tt;
+            const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
+            const double parB = 1e-3 + sr2 * sw / sw2 + snu;
+            S[3] = parB / spd[0];
+        } else {
+            // drawSubjCovarianceCross src/Draw.pl.jl:542-557
+            const double zz = st1[NSTAT1 * J + 0];
+            S[3] = (1e-3 + zz / 2.0) / spd[0];
+        }
+        if (T.cov2one) d_cov2one(S);
+        for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+    }
+    __syncthreads();
+
+    if (T.dbg_stop == 4) return;
     // =========================================================== bookkeeping + item trace
     const bool last_step = (MODEL != CROSSQR) || STEP == 1;
     if (last_step && T.tr_item) {
@@ -732,11 +834,9 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             tr[4 * J + tid] = v;
         }
     }
-    if (tid == 0) {
-        for (int e = 0; e < par_size(J); ++e)
-            if (!(fabs(par[e]) < 1e300) && T.ctl->err == 0u) T.ctl->err = 1u + (uint32_t)e;   // first non-finite entry of the parameter block
-        if (STEP == 0) { T.ctl->sweep = sweep; T.ctl->row = row; }
-    }
+    for (int e = tid; e < par_size(J); e += TINY_THREADS)
+        if (!(fabs(par[e]) < 1e300)) atomicCAS(&T.ctl->err, 0u, 1u + (uint32_t)e);   // a non-finite entry of the parameter block
+    if (tid == 0 && STEP == 0) { T.ctl->sweep = sweep; T.ctl->row = row; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

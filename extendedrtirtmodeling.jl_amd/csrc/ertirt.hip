@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -91,7 +92,7 @@ template <typename real> struct Engine : EngineBase {
     int64_t rows_cap = 0;
     bool has_data = false;
     int W = 8, logW = 3, IPL = 1, block_threads = 1024, grid_blocks = 256;
-    int64_t rows_per_block = 0;
+    int64_t rows_per_block = 0; int rows_per_wave = 0;
     size_t lds_pass[2] = {0, 0};
     int ns[2] = {0, 0};
     uint32_t sweeps_total = 0;
@@ -126,10 +127,9 @@ template <typename real> struct Engine : EngineBase {
         }
     }
     size_t pass_lds(int phase, int nWaves) const {
-        const int R = 64 / W;
         const int ng = stat_sizes(phase) - nstat(phase) * J;
-        size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * ((size_t)nstat(phase) * J + (size_t)ng * R + 1);
-        return d * sizeof(double) + (size_t)NITEMARR * J * sizeof(real);
+        size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * ((size_t)nstat(phase) * J + (size_t)ng);
+        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave) * sizeof(real);
     }
 
     int init() override {
@@ -174,15 +174,15 @@ template <typename real> struct Engine : EngineBase {
         block_threads = cfg.block_threads > 0 ? cfg.block_threads : max_threads;
         if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= 1024 (fp32) / 512 (fp64)");
         const int R = 64 / W;
-        const int64_t nGroups = (N + R - 1) / R;
         const int nWaves = block_threads / 64;
-        const int64_t need = (nGroups + nWaves - 1) / nWaves;
+        const int64_t need = (N + nWaves - 1) / nWaves;         // at least one subject per wave
         const int per_cu = std::max(1, 16 / nWaves);
         grid_blocks = cfg.grid_blocks > 0 ? cfg.grid_blocks : (int)std::min<int64_t>(need, (int64_t)cu_count * per_cu);
         if (grid_blocks < 1) grid_blocks = 1;
-        // each workgroup owns a contiguous range of subjects (a multiple of R so that wave groups never straddle two workgroups)
-        rows_per_block = ((N + grid_blocks - 1) / grid_blocks + R - 1) / R * R;
+        // each workgroup owns a contiguous range of subjects, split evenly over its waves
+        rows_per_block = (N + grid_blocks - 1) / grid_blocks;
         grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
+        rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
         for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
         if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads");
 
@@ -224,6 +224,7 @@ template <typename real> struct Engine : EngineBase {
         std::vector<double> par(par_size(J), 0.0);
         for (int j = 0; j < J; ++j) { par[j] = 1.0; par[3 * J + j] = 1.0; }
         par[par_off_sigp(J) + 0] = 1.0; par[par_off_sigp(J) + 3] = 1.0;
+        par[par_off_derived(J)] = (double)J;
         HIPCHK(hipMemcpy(dPar.p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
         if (dNu.p) {
             std::vector<real> ones(dNu.bytes / sizeof(real), real(1));
@@ -241,7 +242,7 @@ template <typename real> struct Engine : EngineBase {
     }
     size_t tiny_lds() const {
         const int mx = std::max(ns[0], ns[1]);
-        return (size_t)(ns[0] + (cfg.model == ERM_MODEL_CROSSQR ? ns[1] : 0) + 4 * mx + TINY_WORK) * sizeof(double);
+        return (size_t)(ns[0] + (cfg.model == ERM_MODEL_CROSSQR ? ns[1] : 0) + 4 * mx + TINY_WORK + 2 * PMAX * PMAX) * sizeof(double);
     }
     int configure_kernels() {
         switch (cfg.model) {
@@ -274,10 +275,11 @@ template <typename real> struct Engine : EngineBase {
         a.ctl = dCtl.as<Ctl>();
         a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
         a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
-        a.N = N; a.rows_per_block = rows_per_block; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode;
+        a.N = N; a.rows_per_block = rows_per_block; a.rows_per_wave = rows_per_wave; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode;
         a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
+        { const char* e = getenv("ERM_PASS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
         return a;
     }
     TinyArgs tiny_args(int mode, int first) const {
@@ -290,6 +292,7 @@ template <typename real> struct Engine : EngineBase {
         const double q = cfg.q_rt;
         t.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); t.k2 = 2.0 / (q * (1.0 - q));
         t.nq = nq();
+        { const char* e = getenv("ERM_TINY_STOP"); t.dbg_stop = e ? atoi(e) : 0; }
         return t;
     }
 
@@ -498,6 +501,7 @@ template <typename real> struct Engine : EngineBase {
             if (cfg.model == ERM_MODEL_RTIRT) { for (int u = 0; u < pp; ++u) { b[u] = st->beta[u]; b[PMAX + u] = st->beta[pp + u]; } }
             else for (int u = 0; u < nbeta(); ++u) b[u] = st->beta[u];
         }
+        { double t = 0.0; for (int j = 0; j < J; ++j) t += 1.0 / par[3 * J + j]; par[par_off_derived(J)] = t; }
         HIPCHK(hipMemcpy(dPar.p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
         if (st->theta) if (int rc = up_real(dTheta, st->theta, N)) return rc;
         if (st->zeta) if (int rc = up_real(dZeta, st->zeta, N)) return rc;

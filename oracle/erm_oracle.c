@@ -269,7 +269,9 @@ static void draw_zeta(const orc_config* c, const orc_data* d, orc_state* s, uint
     double* m = (double*)malloc(sizeof(double) * c->nSubj), *v = (double*)malloc(sizeof(double) * c->nSubj);
     moments_zeta(c, d, s, m, v);
     for (int64_t i = 0; i < c->nSubj; ++i) {
-        orc_stream st = orc_stream_make(c->seed, c->chain, ORC_SITE_ZETA, (uint32_t)i, 0, sweep);
+        /* one block per subject and sweep feeds both row draws: words 0,1 -> theta's normal, words 2,3 -> zeta's */
+        orc_stream st = orc_stream_make(c->seed, c->chain, ORC_SITE_THETA, (uint32_t)i, 0, sweep);
+        (void)orc_u32(&st); (void)orc_u32(&st);
         s->zeta[i] = m[i] + sqrt(v[i]) * orc_normal(&st);
     }
     free(m); free(v);
