@@ -1,0 +1,49 @@
+"""HIP path against the committed golden fixtures (tests/golden/*.npz: inputs + oracle traces), through the Julia-surface mirror
+(Gibbs* constructors, sample!, Post) where the model allows it."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+from test_oracle_sweeps import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("model", ["mlirt", "rtirt", "latentqr", "crossqr"])
+def test_engine_reproduces_golden_traces(model):
+    z, Y, logT, X, init = load_golden(model)
+    T = int(z["T"]) if model != "crossqr" else 3
+    dev = pu.run_device(model, Y, logT, X, init, T, precision="f64", qRt=float(z["qRt"]), seed=int(z["seed"]))
+    assert pu.rel_err(dev["ra"][:, :, 0], z["ra"][:T]).max() < 1e-8
+    if model != "mlirt":
+        assert pu.rel_err(dev["rt"][:, :, 0], z["rt"][:T]).max() < 1e-8
+    if model != "crossqr":
+        assert pu.rel_err(dev["qr"][:, :, 0], z["qr"][:T]).max() < 1e-8
+    assert pu.rel_err(dev["ll"][:, 0, 0], z["ll"][:T]).max() < 1e-8
+
+
+def test_sample_bang_fills_post_like_the_reference():
+    """GibbsRtIrt(Cond; Data) |> sample! : Post.ra/rt/qr/logLike shapes and layout (src/GibbsRtIrt.pl.jl:63-70), Post.mean flat
+    vectors over m > nBurnin and all chains (:327-343), Para left at the final state, second call continues the chain."""
+    pkg = pu.ge.load_package()
+    z, Y, logT, X, init = load_golden("rtirt")
+    N, J = Y.shape
+    Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=3, nIter=6, nChain=2, qRt=0.5)
+    M = pkg.GibbsRtIrt(Cond, Data=pkg.InputData(Y=Y, T=np.exp(logT), X=X), precision="f64")
+    assert pkg.sample_b(M) is M
+    P = M.Post
+    assert P.ra.shape == (6, N + 2 * J, 2) and P.rt.shape == (6, N + 2 * J, 2) and P.qr.shape == (6, 12, 2) and P.logLike.shape == (6, 1, 2)
+    assert np.allclose(P.mean.theta, P.ra[3:, :N, :].mean(axis=(0, 2))) and np.allclose(P.mean.sig2t, P.rt[3:, N + J:, :].mean(axis=(0, 2)))
+    assert np.allclose(P.mean.beta, P.qr[3:, :8, :].mean(axis=(0, 2))) and P.mean.Sigp.shape == (4,)
+    assert np.array_equal(M.Para.theta, P.ra[5, :N, 1]) and np.array_equal(M.Para.b, P.ra[5, N + J:, 1])
+    assert np.all(P.qr[:, 0, :] == 0) and np.all(P.qr[:, 4, :] == 0)          # intercept=false
+    assert np.all(P.qr[:, 8, :] == 1) and np.all(P.qr[:, 11, :] == 1)         # cov2one=true
+    first = P.ra.copy()
+    pkg.sample_b(M)
+    assert not np.array_equal(first, M.Post.ra)                                # continues from Para with fresh variates
+    d = pkg.getDic(M)
+    assert np.isfinite(d.DIC) and np.isfinite(d.pD)
+    assert set(pkg.coef(M)) >= {"a", "b", "β", "Σp"} and len(pkg.precis(M)["names"]) == 4 * J + 12
+    M1 = pkg.GibbsRtIrt(Cond, Data=M.Data, precision="f64")
+    pkg.sample_b(M1, itemtype="1pl")
+    assert np.all(M1.Post.ra[:, N:N + J, :] == 1)

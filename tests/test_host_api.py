@@ -1,0 +1,103 @@
+"""Host-side mirror of the reference's interface (no GPU needed): containers, setCond quirks, sample! argument validation
+and error text, the C-ABI library loads and exports every symbol include/ertirt.h declares, struct layouts agree."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import parity_util as pu
+
+pkg = pu.ge.load_package()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(pu.ROOT, "include", "ertirt.h")).read()
+    declared = set(re.findall(r"\b(erm_[a-z_]+)\s*\(", hdr))
+    lib = pkg._lib.load()
+    assert declared == set(pkg._lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.erm_version()
+
+
+def test_ctypes_struct_layout_matches_header():
+    # field order and sizes of erm_config / erm_timing as declared in include/ertirt.h
+    assert C.sizeof(pkg._lib.erm_config) == 4 * 2 + 8 + 4 * 9 + 4 + 8 + 8 + 4 * 8     # 108 -> padded
+    assert pkg._lib.erm_config.n_subj.offset == 8 and pkg._lib.erm_config.q_rt.offset == 56 and pkg._lib.erm_config.seed.offset == 64
+    assert C.sizeof(pkg._lib.erm_state) == 10 * C.sizeof(C.c_void_p)
+    assert C.sizeof(pkg._lib.erm_timing) == 8 * 4 + 4 * 6
+
+
+def test_create_without_gpu_reports_an_error_instead_of_falling_back():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg._lib.ErmError):
+        pkg._lib.Engine(model=1, n_item=5, n_subj=10, n_feat=1, n_iter=2, n_chain=1, n_burnin=1)
+
+
+def test_setcond_defaults_and_forced_burnin():
+    c = pkg.setCond()
+    assert (c.nSubj, c.nItem, c.nFeat, c.nIter, c.nChain, c.nThin, c.nRep, c.qRa, c.qRt) == (2000, 15, 3, 5000, 4, 1, 10, 0.5, 0.5)
+    assert c.nBurnin == 2500
+    assert pkg.setCond(nIter=501, nBurnin=7).nBurnin == 250          # kwarg ignored; round half to even like Julia (250.5 -> 250)
+    assert pkg.setCond(nIter=503).nBurnin == 252                      # 251.5 -> 252
+
+
+def test_input_data_derives_kappa_and_logT():
+    Y = np.array([[1, 0], [0, 1], [1, 1]], dtype=bool)
+    T = np.exp(np.array([[1.0, 2.0], [3.0, 4.0], [0.5, 0.25]]))
+    D = pkg.InputData(Y=Y, T=T, X=np.ones((3, 1)))
+    assert np.array_equal(D.κ, Y - 0.5) and np.allclose(D.logT, np.log(T))
+    P = pkg.InputPara(θ=[1, 2], Σp=np.eye(2))
+    assert np.array_equal(P.theta, [1, 2]) and np.array_equal(getattr(P, "σ²t"), []) and P.Sigp.shape == (2, 2)
+    with pytest.raises(AttributeError):
+        P.nonsense = 1
+
+
+def _toy(cls, **kw):
+    Cond = pkg.setCond(nSubj=30, nItem=4, nFeat=2, nIter=6, nChain=2, qRt=0.85)
+    g = np.random.default_rng(0)
+    D = pkg.InputData(Y=g.random((30, 4)) < 0.5, T=np.exp(g.normal(1, 0.3, (30, 4))), X=g.standard_normal((30, 2)))
+    return cls(Cond, Data=D, **kw)
+
+
+def test_constructors_initialise_para_like_the_reference():
+    M = _toy(pkg.GibbsRtIrt)
+    assert M.Para.theta.shape == (30,) and M.Para.zeta.shape == (30,) and M.Para.beta.shape == (3, 2)
+    assert np.all(M.Para.a == 1) and np.all(M.Para.b == 0) and np.all(M.Para.lam == 0) and np.all(M.Para.sig2t == 1)
+    assert np.array_equal(M.Para.Sigp, np.eye(2))
+    assert _toy(pkg.GibbsMlIrt).Para.beta.shape == (3,) and _toy(pkg.GibbsMlIrt).Para.Sigp.size == 0
+    assert _toy(pkg.GibbsRtIrtLatentQr).Para.beta.shape == (4,)
+    assert _toy(pkg.GibbsRtIrtCrossQr).Para.rho.shape == (4,)
+    assert pkg.GibbsRtIrtQuantile is pkg.GibbsRtIrtLatentQr
+    # same seed -> same initial values; different chain_id -> different
+    assert np.array_equal(_toy(pkg.GibbsRtIrt, seed=5).Para.theta, _toy(pkg.GibbsRtIrt, seed=5).Para.theta)
+    assert not np.array_equal(_toy(pkg.GibbsRtIrt, seed=5).Para.theta, _toy(pkg.GibbsRtIrt, seed=5, chain_id=1).Para.theta)
+
+
+def test_sample_validates_itemtype_with_the_reference_error_text():
+    M = _toy(pkg.GibbsRtIrt)
+    with pytest.raises(ValueError, match="Invalid input: the item type must be '1pl' or '2pl'."):
+        pkg.sample_b(M, itemtype="3pl")
+    with pytest.raises(TypeError):
+        pkg.sample_b(_toy(pkg.GibbsRtIrtCrossQr), intercept=True)     # sample!(::GibbsRtIrtCrossQr) has no intercept kwarg
+    assert pkg.sample is pkg.sample_b
+
+
+def test_simtools_generators_shapes_and_ranges():
+    Cond = pkg.setCond(nSubj=500, nItem=6, nFeat=3, nIter=4, nChain=1)
+    for tp_fn, d_fn in ((pkg.setTrueParaRtIrt, pkg.setDataRtIrt), (pkg.setTrueParaRtIrtCross, pkg.setDataRtIrtCross),
+                        (pkg.setTrueParaRtIrtLatent, pkg.setDataRtIrtLatent)):
+        tp = tp_fn(Cond, seed=1)
+        D = d_fn(Cond, tp, seed=2)
+        assert D.Y.shape == (500, 6) and set(np.unique(D.Y)) <= {0, 1} and D.logT.shape == (500, 6) and np.all(np.isfinite(D.logT))
+        assert np.all(tp.a > 0) and tp.theta.shape == (500,)
+    D = pkg.setDataRtIrt(Cond, pkg.setTrueParaRtIrt(Cond, seed=1), seed=2)
+    assert D.logT.min() >= 0                                            # truncated at 0, src/SimTools.jl:169
+    tp = pkg.setTrueParaMlIrt(Cond, seed=1)
+    D = pkg.setDataMlIrt(Cond, tp, seed=2)
+    assert set(np.unique(D.X[:, 0])) <= {0.0, 1.0}
+    assert pkg.getRmse([1, 2], [1, 4]) == pytest.approx(np.sqrt(2)) and pkg.getBias([1, 2], [1, 4]) == -1
