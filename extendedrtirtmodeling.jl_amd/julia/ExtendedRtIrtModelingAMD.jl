@@ -1,0 +1,167 @@
+# ExtendedRtIrtModelingAMD.jl -- Julia-side drop-in for the `sample!` hot path of ExtendedRtIrtModeling.jl, backed by
+# libertirt.so (include/ertirt.h).  SHIPS AS SOURCE, UNTESTED: no Julia toolchain exists in the build container or on
+# the GPU box (SURVEY.md 8(b)); the same C ABI is exercised by the Python ctypes host in this package, whose tests are
+# the parity tests.  See INTEGRATION.md for how a maintainer wires this into the reference package.
+#
+# What it replaces (paths relative to the reference repository):
+#   sample!(::GibbsMlIrt)          src/GibbsRtIrt.pl.jl:210-257
+#   sample!(::GibbsRtIrt)          src/GibbsRtIrt.pl.jl:278-346
+#   sample!(::GibbsRtIrtCrossQr)   src/GibbsRtIrtCross.pl.jl:265-325
+#   sample!(::GibbsRtIrtLatentQr)  src/GibbsRtIrtLatent.pl.jl:271-337
+# Struct names, fields, constructor behaviour, kwargs, error text and the Post layout are the reference's; coef / precis /
+# getDic / comparePara / checkConvergence of the reference keep working on the filled `Post`.
+module ExtendedRtIrtModelingAMD
+
+using LinearAlgebra, Random
+
+export sample!, GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCrossQr, GibbsRtIrtLatentQr, GibbsRtIrtQuantile, libertirt_path!
+
+const LIB = Ref{String}(get(ENV, "LIBERTIRT", "libertirt.so"))
+libertirt_path!(p::AbstractString) = (LIB[] = String(p))
+
+# ---- mirror of erm_config / erm_state / erm_timing (include/ertirt.h); field order and types must match exactly
+struct ErmConfig
+    model::Int32; n_item::Int32; n_subj::Int64; n_feat::Int32; n_iter::Int32; n_chain::Int32; n_burnin::Int32
+    intercept::Int32; one_pl::Int32; cov2one::Int32; sigp_mode::Int32; chain_id::Int32; q_rt::Float64; seed::UInt64
+    device::Int32; precision::Int32; trace_mode::Int32; lanes_per_row::Int32; block_threads::Int32; grid_blocks::Int32
+    profile::Int32; reserved::Int32
+end
+struct ErmState
+    theta::Ptr{Float64}; a::Ptr{Float64}; b::Ptr{Float64}; zeta::Ptr{Float64}; lambda::Ptr{Float64}; sig2t::Ptr{Float64}
+    beta::Ptr{Float64}; sigp::Ptr{Float64}; rho::Ptr{Float64}; nu::Ptr{Float64}
+end
+const MODEL_MLIRT, MODEL_RTIRT, MODEL_CROSSQR, MODEL_LATENTQR = Int32(0), Int32(1), Int32(2), Int32(3)
+const TRACE_RA, TRACE_RT, TRACE_QR, TRACE_LOGLIKE = Int32(0), Int32(1), Int32(2), Int32(3)
+
+lasterr() = unsafe_string(ccall((:erm_last_error, LIB[]), Cstring, ()))
+check(rc::Integer) = rc == 0 ? nothing : error("libertirt: " * lasterr())
+
+# ---- the reference's containers (src/Base.pl.jl:100-115), reproduced so the module is self-contained when used stand-alone;
+# inside the reference package these definitions are simply dropped in favour of the existing ones.
+Base.@kwdef mutable struct InputPara
+    ω::Array = Float64[]; θ::Array = Float64[]; a::Array = Float64[]; b::Array = Float64[]; ζ::Array = Float64[]
+    λ::Array = Float64[]; σ²t::Array = Float64[]; ν::Array = Float64[]; β::Array = Float64[]; ρ::Array = Float64[]; Σp::Array = Float64[]
+end
+mutable struct OutputPost
+    ra; rt; qr; logLike; mean
+end
+
+abstract type GibbsAMD end
+for (T, model) in ((:GibbsMlIrt, MODEL_MLIRT), (:GibbsRtIrt, MODEL_RTIRT), (:GibbsRtIrtCrossQr, MODEL_CROSSQR), (:GibbsRtIrtLatentQr, MODEL_LATENTQR))
+    @eval begin
+        mutable struct $T <: GibbsAMD
+            Cond; Data; truePara; Para; Post
+            handle::Ptr{Cvoid}; key::Any; seed::UInt64; device::Int32; precision::Int32
+            function $T(Cond; Data = [], truePara = [], Para = Float64[], Post = Float64[], seed = 1234, device = 0, precision = 0)
+                obj = new(Cond, Data, truePara, Para, Post, C_NULL, nothing, UInt64(seed), Int32(device), Int32(precision))
+                setInitialValues(obj)                      # always overwrites Para, as the reference's constructors do
+                obj.Post = OutputPost([], [], [], [], Float64[])
+                finalizer(o -> (o.handle != C_NULL && ccall((:erm_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), o.handle)), obj)
+                return obj
+            end
+        end
+        modelid(::$T) = $model
+    end
+end
+const GibbsRtIrtQuantile = GibbsRtIrtLatentQr     # README.md:22,95; the reference's export is commented out (src/ExtendedRtIrtModeling.jl:65)
+
+# setInitialValues: src/GibbsRtIrt.pl.jl:84-93,122-133; src/GibbsRtIrtCross.pl.jl:123-134; src/GibbsRtIrtLatent.pl.jl:113-124
+function setInitialValues(s::GibbsMlIrt)
+    C = s.Cond
+    s.Para = InputPara(θ = randn(C.nSubj), a = ones(C.nItem), b = zeros(C.nItem), β = randn(C.nFeat + 1)); s
+end
+function setInitialValues(s::GibbsRtIrt)
+    C = s.Cond
+    s.Para = InputPara(θ = randn(C.nSubj), a = ones(C.nItem), b = zeros(C.nItem), ζ = randn(C.nSubj), λ = zeros(C.nItem),
+                       σ²t = ones(C.nItem), β = randn(C.nFeat + 1, 2), Σp = Matrix{Float64}(I, 2, 2)); s
+end
+function setInitialValues(s::GibbsRtIrtCrossQr)
+    C = s.Cond
+    s.Para = InputPara(θ = randn(C.nSubj), a = ones(C.nItem), b = zeros(C.nItem), ζ = randn(C.nSubj), λ = zeros(C.nItem),
+                       σ²t = ones(C.nItem), ρ = randn(C.nItem), Σp = Matrix{Float64}(I, 2, 2)); s
+end
+function setInitialValues(s::GibbsRtIrtLatentQr)
+    C = s.Cond
+    s.Para = InputPara(θ = randn(C.nSubj), a = ones(C.nItem), b = zeros(C.nItem), ζ = randn(C.nSubj), λ = zeros(C.nItem),
+                       σ²t = ones(C.nItem), β = randn(C.nFeat + 2), Σp = Matrix{Float64}(I, 2, 2)); s
+end
+
+dense(x) = isempty(x) ? Float64[] : Array{Float64}(x)
+ptr(x::Array{Float64}) = isempty(x) ? Ptr{Float64}(C_NULL) : pointer(x)
+
+function engine!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool)
+    key = (intercept, onepl, cov2one)
+    M.handle != C_NULL && M.key == key && return M.handle
+    M.handle != C_NULL && ccall((:erm_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), M.handle)
+    C = M.Cond
+    cfg = ErmConfig(modelid(M), C.nItem, C.nSubj, C.nFeat, C.nIter, C.nChain, C.nBurnin, intercept, onepl, cov2one, 0, 0, C.qRt,
+                    M.seed, M.device, M.precision, 1, 0, 0, 0, 0, 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:erm_create, LIB[]), Cint, (Ref{ErmConfig}, Ref{Ptr{Cvoid}}), cfg, h))
+    Y = Array{UInt8}(M.Data.Y)                                  # Matrix{Bool} from setData* or a 0/1 numeric matrix
+    logT = modelid(M) == MODEL_MLIRT ? Float64[] : dense(M.Data.logT)
+    X = (modelid(M) == MODEL_CROSSQR || C.nFeat == 0) ? Float64[] : dense(M.Data.X)
+    GC.@preserve Y logT X check(ccall((:erm_set_data, LIB[]), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}), h[], Y, ptr(logT), ptr(X)))
+    M.handle, M.key = h[], key
+    return M.handle
+end
+
+function state_arrays(P::InputPara)
+    (dense(P.θ), dense(P.a), dense(P.b), dense(P.ζ), dense(P.λ), dense(P.σ²t), dense(vec(P.β)), dense(vec(P.Σp)), dense(P.ρ), dense(vec(P.ν)))
+end
+
+"""
+    sample!(MCMC; intercept=false, itemtype="2pl", cov2one)
+
+Same contract as the reference's `sample!`: runs `Cond.nIter * Cond.nChain` sweeps of the interleaved loop, fills
+`MCMC.Post.{ra,rt,qr,logLike,mean}`, leaves the final state in `MCMC.Para`, returns `MCMC`.
+"""
+function sample!(M::GibbsAMD; intercept = false, itemtype::Union{String} = "2pl",
+                 cov2one = !(M isa GibbsRtIrtLatentQr))
+    if !(itemtype in ["1pl", "2pl"])
+        error("Invalid input: the item type must be '1pl' or '2pl'.")
+    end
+    C = M.Cond
+    h = engine!(M, intercept, itemtype == "1pl", cov2one)
+    check(ccall((:erm_reset_trace, LIB[]), Cint, (Ptr{Cvoid},), h))
+    arrs = state_arrays(M.Para)
+    GC.@preserve arrs begin
+        st = ErmState(map(ptr, arrs)...)
+        check(ccall((:erm_set_state, LIB[]), Cint, (Ptr{Cvoid}, Ref{ErmState}), h, st))
+    end
+    check(ccall((:erm_run, LIB[]), Cint, (Ptr{Cvoid}, Int64), h, C.nIter * C.nChain))
+
+    trace(which) = begin
+        w = ccall((:erm_trace_width, LIB[]), Int64, (Ptr{Cvoid}, Cint), h, which)
+        out = Array{Float64}(undef, C.nIter, w, C.nChain)
+        check(ccall((:erm_get_trace, LIB[]), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), h, which, out)); out
+    end
+    Post = M.Post
+    Post.ra = trace(TRACE_RA)
+    Post.logLike = trace(TRACE_LOGLIKE)
+    modelid(M) != MODEL_MLIRT && (Post.rt = trace(TRACE_RT))
+    modelid(M) != MODEL_CROSSQR && (Post.qr = trace(TRACE_QR))   # CrossQr: only the running mean of nu is kept on the device
+
+    N, J, F = C.nSubj, C.nItem, C.nFeat
+    nb = modelid(M) == MODEL_MLIRT ? F + 1 : modelid(M) == MODEL_RTIRT ? 2 * (F + 1) : modelid(M) == MODEL_LATENTQR ? F + 2 : 0
+    nnu = modelid(M) == MODEL_LATENTQR ? N : modelid(M) == MODEL_CROSSQR ? N * J : 0
+    bufs = (zeros(N), zeros(J), zeros(J), zeros(N), zeros(J), zeros(J), zeros(nb), zeros(4), zeros(J), zeros(nnu))
+    GC.@preserve bufs begin
+        check(ccall((:erm_get_mean, LIB[]), Cint, (Ptr{Cvoid}, Ref{ErmState}), h, ErmState(map(ptr, bufs)...)))
+    end
+    Post.mean = InputPara(θ = bufs[1], a = bufs[2], b = bufs[3], ζ = bufs[4], λ = bufs[5], σ²t = bufs[6], β = bufs[7], Σp = bufs[8], ρ = bufs[9], ν = bufs[10])
+    GC.@preserve bufs begin
+        check(ccall((:erm_get_state, LIB[]), Cint, (Ptr{Cvoid}, Ref{ErmState}), h, ErmState(map(ptr, bufs)...)))
+    end
+    P = M.Para
+    P.θ, P.a, P.b = copy(bufs[1]), copy(bufs[2]), copy(bufs[3])
+    if modelid(M) != MODEL_MLIRT
+        P.ζ, P.λ, P.σ²t, P.Σp = copy(bufs[4]), copy(bufs[5]), copy(bufs[6]), reshape(copy(bufs[8]), 2, 2)
+    end
+    nb > 0 && (P.β = modelid(M) == MODEL_RTIRT ? reshape(copy(bufs[7]), F + 1, 2) : copy(bufs[7]))
+    modelid(M) == MODEL_CROSSQR && (P.ρ = copy(bufs[9]); P.ν = reshape(copy(bufs[10]), N, J))
+    modelid(M) == MODEL_LATENTQR && (P.ν = copy(bufs[10]))
+    return M
+end
+
+end # module
