@@ -59,6 +59,7 @@ template <typename real> struct PassArgs {
     const uint8_t* Y; const real* C; real* omega; real* nu; const real* X;
     real* theta; real* zeta;
     const double* par; const double* cst; double* slab; const Ctl* ctl;
+    double* gslab; unsigned int* gcnt;              // per-group reduced slabs and arrival counters (GROUP consecutive workgroups)
     double* sum_theta; double* sum_zeta; double* sum_nu;
     real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] or nullptr
     long long N; long long rows_per_block;          // each workgroup owns rows [b*rpb, (b+1)*rpb)
@@ -94,6 +95,7 @@ __device__ __forceinline__ float  log1pexp_r(float x)  { return fmaxf(x, 0.f) + 
 __device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
 constexpr double LOG_2PI = 1.8378770664093454836;
+constexpr int GROUP = 16;  // workgroups whose slab rows are summed by the last of them to finish
 constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -484,7 +486,41 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         double t = 0.0;
         if (e < NSTAT * J) { for (int w = 0; w < nWaves; ++w) t += sh_acc[(size_t)w * NSTAT * J + e]; }
         else { const int gi = e - NSTAT * J; for (int w = 0; w < nWaves; ++w) t += sh_gacc[(size_t)w * NG + gi]; }
-        out[e] = t;
+        __hip_atomic_store(out + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through (sc1) store: no release fence needed
+    }
+    // ---- hierarchical reduction: the LAST workgroup of each group of GROUP consecutive ones to arrive sums the group's slab rows
+    // in workgroup order (fixed order => deterministic), so the tiny step reads ceil(grid/GROUP) rows instead of grid rows.
+    // Hand-off per cdna_hip_programming.md Guideline 16 (form R1): the slab row is stored write-through (sc1), every storing
+    // wave drains its stores, workgroup barrier, one lane takes a ticket with an agent-scope atomic; the last arriver acquires
+    // at agent scope (L1 invalidate) before any of its waves loads.  No L2 write-back (release fence) is needed, which matters
+    // because each workgroup has just dirtied its whole omega slice.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* sh_flag = reinterpret_cast<int*>(sh_struct);       // sh_struct is dead by now
+    const int grp = blockIdx.x / GROUP;
+    const int gfirst = grp * GROUP;
+    const int gcount = ((int)gridDim.x - gfirst < GROUP) ? (int)gridDim.x - gfirst : GROUP;
+    if (threadIdx.x == 0) {
+        const unsigned int ticket = __hip_atomic_fetch_add(A.gcnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket == (unsigned int)(gcount - 1)) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        sh_flag[0] = last;
+    }
+    __syncthreads();
+    if (sh_flag[0]) {
+        double* gout = A.gslab + (size_t)grp * NS;
+        for (int e = threadIdx.x; e < NS; e += blockDim.x) {
+            double v[GROUP];
+#pragma unroll
+            for (int b = 0; b < GROUP; ++b) v[b] = A.slab[(size_t)(gfirst + (b < gcount ? b : 0)) * NS + e];   // all loads in flight
+            double t = 0.0;
+#pragma unroll
+            for (int b = 0; b < GROUP; ++b) t += (b < gcount) ? v[b] : 0.0;
+            gout[e] = t;
+        }
     }
 }
 
@@ -493,6 +529,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
 // ---------------------------------------------------------------------------------------------------------------------
 struct TinyArgs {
     double* par; const double* cst; const double* slab0; const double* slab1; Ctl* ctl;
+    unsigned int* gcnt0; unsigned int* gcnt1;       // arrival counters of the pass kernels, re-armed here
     double* tr_item;      // [rows][4J + NQ] : a, b, lambda, sig2t, then the small part of qr
     double* tr_ll;        // [rows]
     long long N; int J; int nFeat; int nb0, nb1;
@@ -559,6 +596,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
         for (int e = tid; e < NS; e += TINY_THREADS) out[e] = (part[e] + part[NS + e]) + (part[2 * NS + e] + part[3 * NS + e]);
         __syncthreads();
     };
+    if (tid < T.nb0) T.gcnt0[tid] = 0u;                     // re-arm the group counters for the next pass (kernel boundary orders this)
+    if (MODEL == CROSSQR && tid < T.nb1) T.gcnt1[tid] = 0u;
     reduce(T.slab0, T.nb0, NS0, st0);
     if (MODEL == CROSSQR && STEP == 0) reduce(T.slab1, T.nb1, NS1, st1);
 

@@ -97,10 +97,12 @@ template <typename real> struct Engine : EngineBase {
     int ns[2] = {0, 0};
     uint32_t sweeps_total = 0;
 
-    DevBuf dY, dC, dOmega, dNu, dX, dTheta, dZeta, dPar, dCst, dSlab0, dSlab1, dCtl;
+    DevBuf dY, dC, dOmega, dNu, dX, dTheta, dZeta, dPar, dCst, dSlab0, dSlab1, dCtl, dGslab0, dGslab1, dGcnt;
+    int n_groups = 1;
     DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
 
     ~Engine() override {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         for (auto e : pass_ev) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -200,8 +202,12 @@ template <typename real> struct Engine : EngineBase {
         rc |= dZeta.alloc((size_t)N * sizeof(real));
         rc |= dPar.alloc((size_t)par_size(J) * sizeof(double));
         rc |= dCst.alloc((size_t)cst_size(J) * sizeof(double));
+        n_groups = (grid_blocks + GROUP - 1) / GROUP;
+        if (n_groups > TINY_THREADS) return fail(ERM_ERR_ARG, "grid too large");
         rc |= dSlab0.alloc((size_t)grid_blocks * ns[0] * sizeof(double));
-        if (cfg.model == ERM_MODEL_CROSSQR) rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double));
+        rc |= dGslab0.alloc((size_t)n_groups * ns[0] * sizeof(double));
+        rc |= dGcnt.alloc((size_t)2 * n_groups * sizeof(unsigned int));
+        if (cfg.model == ERM_MODEL_CROSSQR) { rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double)); rc |= dGslab1.alloc((size_t)n_groups * ns[1] * sizeof(double)); }
         rc |= dCtl.alloc(sizeof(Ctl));
         rc |= dSumTheta.alloc((size_t)N * sizeof(double));
         rc |= dSumZeta.alloc((size_t)N * sizeof(double));
@@ -272,6 +278,8 @@ template <typename real> struct Engine : EngineBase {
         a.theta = dTheta.as<real>(); a.zeta = dZeta.as<real>();
         a.par = dPar.as<double>(); a.cst = dCst.as<double>();
         a.slab = phase == 0 ? dSlab0.as<double>() : dSlab1.as<double>();
+        a.gslab = phase == 0 ? dGslab0.as<double>() : dGslab1.as<double>();
+        a.gcnt = dGcnt.as<unsigned int>() + (phase == 0 ? 0 : n_groups);
         a.ctl = dCtl.as<Ctl>();
         a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
         a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
@@ -284,9 +292,10 @@ template <typename real> struct Engine : EngineBase {
     }
     TinyArgs tiny_args(int mode, int first) const {
         TinyArgs t{};
-        t.par = dPar.as<double>(); t.cst = dCst.as<double>(); t.slab0 = dSlab0.as<double>(); t.slab1 = dSlab1.as<double>();
+        t.par = dPar.as<double>(); t.cst = dCst.as<double>(); t.slab0 = dGslab0.as<double>(); t.slab1 = dGslab1.as<double>();
+        t.gcnt0 = dGcnt.as<unsigned int>(); t.gcnt1 = dGcnt.as<unsigned int>() + n_groups;
         t.ctl = dCtl.as<Ctl>(); t.tr_item = dTrItem.as<double>(); t.tr_ll = dTrLl.as<double>();
-        t.N = N; t.J = J; t.nFeat = Fk; t.nb0 = grid_blocks; t.nb1 = grid_blocks; t.mode = mode; t.first = first;
+        t.N = N; t.J = J; t.nFeat = Fk; t.nb0 = n_groups; t.nb1 = n_groups; t.mode = mode; t.first = first;
         t.intercept = cfg.intercept; t.onepl = cfg.one_pl; t.cov2one = cfg.cov2one; t.sigp_mode = cfg.sigp_mode;
         t.chain = (uint32_t)cfg.chain_id; t.seed = cfg.seed;
         const double q = cfg.q_rt;
@@ -311,18 +320,44 @@ template <typename real> struct Engine : EngineBase {
         return 0;
     }
 
+    // One sweep = tiny step + row pass (CrossQr: two of each).  Kernel arguments never change between sweeps (sweep / trace-row
+    // counters live in device memory), so a block of GRAPH_SWEEPS sweeps is captured once into a hipGraph and replayed; this
+    // removes the per-launch host overhead that otherwise leaves the GPU idle between the short kernels.
+    static constexpr int GRAPH_SWEEPS = 32;
+    hipGraphExec_t graph_exec = nullptr;
+    template <int MODEL> int enqueue_sweep(bool first, bool timed) {
+        if (int rc = launch_tiny<MODEL, 0>(0, first)) return rc;
+        if (int rc = launch_pass<MODEL, 0>(1, timed)) return rc;
+        if constexpr (MODEL == CROSSQR) {
+            if (int rc = launch_tiny<MODEL, 1>(0, 0)) return rc;
+            if (int rc = launch_pass<MODEL, 1>(1, timed)) return rc;
+        }
+        return 0;
+    }
+    template <int MODEL> int build_graph() {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int rc = 0;
+        for (int k = 0; k < GRAPH_SWEEPS && !rc; ++k) rc = enqueue_sweep<MODEL>(false, false);
+        hipError_t e = hipStreamEndCapture(stream, &g);
+        if (rc) return rc;
+        HIPCHK(e);
+        HIPCHK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
+        HIPCHK(hipGraphDestroy(g));
+        return 0;
+    }
     template <int MODEL> int run_model(int64_t nsweeps) {
         // prologue: omega_{t+1} (and nu_{t+1}) and the statistics of the current state
         if (int rc = launch_pass<MODEL, 0>(0, false)) return rc;
         if constexpr (MODEL == CROSSQR) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
-        for (int64_t k = 0; k < nsweeps; ++k) {
-            if (int rc = launch_tiny<MODEL, 0>(0, k == 0)) return rc;
-            if (int rc = launch_pass<MODEL, 0>(1, true)) return rc;
-            if constexpr (MODEL == CROSSQR) {
-                if (int rc = launch_tiny<MODEL, 1>(0, 0)) return rc;
-                if (int rc = launch_pass<MODEL, 1>(1, true)) return rc;
-            }
+        int64_t k = 0;
+        if (nsweeps > 0) { if (int rc = enqueue_sweep<MODEL>(true, true)) return rc; k = 1; }
+        const bool use_graph = !cfg.profile && getenv("ERM_NO_GRAPH") == nullptr;
+        if (use_graph && nsweeps - k >= GRAPH_SWEEPS) {
+            if (!graph_exec) { if (int rc = build_graph<MODEL>()) return rc; }
+            for (; nsweeps - k >= GRAPH_SWEEPS; k += GRAPH_SWEEPS) HIPCHK(hipGraphLaunch(graph_exec, stream));
         }
+        for (; k < nsweeps; ++k) { if (int rc = enqueue_sweep<MODEL>(false, true)) return rc; }
         if (int rc = launch_tiny<MODEL, 0>(1, nsweeps == 0)) return rc;
         return 0;
     }
