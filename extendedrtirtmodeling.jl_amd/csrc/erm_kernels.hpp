@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 uint32_t w0, w1, w2, w3;
                 philox4x32_10((uint32_t)(ra + rr), (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
                 real w;
-                const bool acc_ = pg1_attempt<real>(z, w0, w1, w2, w3, w);
+                const bool acc_ = pg1_attempt(z, w0, w1, w2, w3, w);
                 if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
                     om[c] = w;
                     c += 64; rr += qJ; j += rJ; att = 0;

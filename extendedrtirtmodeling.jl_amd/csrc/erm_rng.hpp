@@ -240,6 +240,64 @@ __device__ __forceinline__ bool pg1_attempt(real z, uint32_t w0, uint32_t w1, ui
     return true;
 }
 
+// fp32 fast path of the same attempt: algebraically identical, arranged as near-straight-line code for a 64-wide wave.
+//   * the mixture test u0 < p/(p+q) is evaluated as u0 (p+q) < p (no reciprocal);
+//   * ONE log serves both the exponential tail (-log u1) and the quantile polynomial (-log 4p(1-p)); 1/K is shared by p and the tail;
+//   * small-z lanes know 1/x = Z^2, so the series exponent needs no reciprocal;
+//   * the rare large-z proposal (z >= 1/t) and the w >= 5 branch of the quantile polynomial sit behind wave-uniform guards.
+__device__ __forceinline__ bool pg1_attempt(float z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, float& out)
+{
+    const float t = 0.64f, PI = 3.14159265358979f;
+    const float K = fmaf(0.5f * z, z, 0.125f * PI * PI);
+    const float rK = r_rcp(K);
+    const float p = (0.5f * PI) * rK * r_exp(-K * t);
+    const bool large = z >= 1.5625f;
+    float q = 0.42259909466742100f;
+    if (__any(large)) q = large ? 2.0f * r_exp(-z) : q;
+    const float u0 = word_to_unif<float>(w0), u1 = word_to_unif<float>(w1), u2 = word_to_unif<float>(w2), V = word_to_unif<float>(w3);
+    const bool tail = u0 * (p + q) < p;
+    const float pin = large ? u1 : u1 * 0.10564977366685525f;
+    const float L = -r_log(tail ? u1 : 4.0f * pin * (1.0f - pin));
+    // quantile polynomial (Giles): central branch always, far branch only if some lane needs it
+    float wc = L - 2.5f;
+    float pl = 2.81022636e-08f; pl = fmaf(pl, wc, 3.43273939e-07f); pl = fmaf(pl, wc, -3.5233877e-06f); pl = fmaf(pl, wc, -4.39150654e-06f);
+    pl = fmaf(pl, wc, 0.00021858087f); pl = fmaf(pl, wc, -0.00125372503f); pl = fmaf(pl, wc, -0.00417768164f); pl = fmaf(pl, wc, 0.246640727f);
+    pl = fmaf(pl, wc, 1.50140941f);
+    if (__any(!tail && L >= 5.0f)) {
+        const float wf = r_sqrt(L) - 3.0f;
+        float pf = -0.000200214257f; pf = fmaf(pf, wf, 0.000100950558f); pf = fmaf(pf, wf, 0.00134934322f); pf = fmaf(pf, wf, -0.00367342844f);
+        pf = fmaf(pf, wf, 0.00573950773f); pf = fmaf(pf, wf, -0.0076224613f); pf = fmaf(pf, wf, 0.00943887047f); pf = fmaf(pf, wf, 1.00167406f);
+        pf = fmaf(pf, wf, 2.83297682f);
+        pl = (L >= 5.0f) ? pf : pl;
+    }
+    const float nz = 1.41421356237f * pl * (2.0f * pin - 1.0f);     // Phi^-1(pin)
+    const float nz2 = nz * nz;
+    // small-z left proposal: X = 1/Z^2, kept with probability e^{-z^2 X/2}
+    float x = r_rcp(nz2);
+    bool ok = !(u2 > r_exp(-0.5f * z * z * x));
+    float e1 = -2.0f * nz2;                                          // series exponent -2/x
+    if (__any(large && !tail)) {
+        // IG(1/z, 1) by Michael-Schucany-Haas, rejected beyond t
+        const float mu = r_rcp(z), ww = mu * nz2;
+        const float sq = r_sqrt(ww) * r_sqrt(4.0f + ww), den = sq + ww;
+        const float qq = den > 0.0f ? r_div(2.0f * r_sqrt(ww), den) : 1.0f;
+        const float x1 = mu * qq * qq;
+        const float xl = (u2 >= r_div(mu, mu + x1)) ? r_div(mu * mu, x1) : x1;
+        if (large) { x = xl; ok = !(xl > t); e1 = -2.0f * r_rcp(xl); }
+    }
+    if (tail) { x = fmaf(L, rK, t); ok = true; e1 = -0.5f * PI * PI * x; }
+    out = 0.25f * x;
+    if (!ok) return false;
+    float S = 1.0f - 3.0f * r_exp(2.0f * e1);
+    if (V <= S) return true;
+    for (int n = 2; n <= 200; ++n) {
+        const float rho = (float)(2 * n + 1) * r_exp((float)(n * (n + 1)) * e1);
+        if (n & 1) { S -= rho; if (V <= S) return true; }
+        else       { S += rho; if (V > S) return false; }
+    }
+    return true;
+}
+
 // draw addressed by a stream: attempt k consumes block k
 template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c)
 {
@@ -247,7 +305,7 @@ template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c)
     real out = real(0);
     for (int tries = 0; tries < MAX_TRIES; ++tries) {
         const uint32_t w0 = s.next(), w1 = s.next(), w2 = s.next(), w3 = s.next();
-        if (pg1_attempt<real>(z, w0, w1, w2, w3, out)) break;
+        if (pg1_attempt(z, w0, w1, w2, w3, out)) break;
     }
     return out;
 }
