@@ -28,6 +28,7 @@ struct Ctl {
     uint32_t row;         // trace row of that sweep within the current sample! call
     uint32_t burn_rows;   // rows < burn_rows are burn-in (not accumulated into Post.mean)
     uint32_t err;         // sticky non-finite flag
+    unsigned long long dbg_attempts, dbg_trips, dbg_cells;   // diagnostics (ERM_PASS_STOP=9): PG attempts, wave trips, cells
 };
 
 // parameter block written by the tiny step (fp64): a, b, lambda, sig2t, rho : 5 x J, then Sigp(4), beta(2*PMAX),
@@ -233,9 +234,22 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         real nu_row = real(1);
         if (MODEL == LATENTQR) nu_row = A.nu[i];
         real mu0a = 0, mu0b = 0;
+        real xr[8];                                         // first 8 covariates of the subject, loaded once (all loads up front)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xr[u] = (PHASE == 0 && MODEL != CROSSQR && u < F) ? gX[(size_t)i * F + u] : real(0);
+        auto xcol = [&](int u) -> real {                    // column u of [1 X]
+            if (u == 0) return real(1);
+            real v = real(0);
+            if (u <= 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v = (q == u - 1) ? xr[q] : v;
+                return v;
+            }
+            return gX[(size_t)i * F + (u - 1)];
+        };
         if (PHASE == 0 && MODEL != CROSSQR) {
             for (int u = 0; u < p; ++u) {
-                const real xu = (u == 0) ? real(1) : gX[(size_t)i * F + (u - 1)];
+                const real xu = xcol(u);
                 mu0a += xu * (real)beta[u];
                 if (MODEL == RTIRT) mu0b += xu * (real)beta[PMAX + u];
             }
@@ -319,7 +333,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             const double thd = (double)th, zed = (double)ze, nud = (double)nu_next, upd = zed - (double)k1 * nud;
             auto val = [&](int code) -> double {
                 if (code == 0) return 1.0;
-                if (code <= F) return (double)gX[(size_t)i * F + (code - 1)];
+                if (code <= F) return (double)xcol(code);
                 if (code == cT) return thd;
                 if (code == cZ) return zed;
                 if (code == cU) return upd;
@@ -361,15 +375,29 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     if constexpr (PHASE == 0) {
         wave_sync();                                  // sh_th written above
         const int ncell = (int)(rb - ra) * J;
-        const int qJ = 64 / J, rJ = 64 % J;
-        int c = lane, rr = lane / J, j = lane % J;
+        const float invJ = 1.0f / (float)J;
+        // cells are handed out dynamically from a wave-shared LDS counter: a lane that finishes a cell grabs the next index, so
+        // every lane stays busy until the slice is exhausted (which lane draws which cell does not matter: draws are addressed
+        // by (i, j, sweep), never by lane)
+        unsigned int* qhead = reinterpret_cast<unsigned int*>(sh_rs);      // the row sums are dead by now
+        if (lane == 0) *qhead = 64u;
+        wave_sync();
+        auto locate = [&](int c, int& rr, int& j) {      // c -> (row within slice, item); exact for c < 2^22
+            rr = (int)(((float)c + 0.5f) * invJ);
+            j = c - rr * J;
+            if (j < 0) { j += J; --rr; } else if (j >= J) { j -= J; ++rr; }
+        };
+        int c = lane, rr, j;
+        locate(c, rr, j);
         bool active = c < ncell;
         uint32_t att = 0;
         real th = active ? sh_th[rr] : real(0);
         real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
         real* om = A.omega + (size_t)ra * J;
         const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
+        unsigned int n_att = 0, n_trip = 0;
         while (__any(active)) {
+            ++n_trip; n_att += active ? 1u : 0u;
             if (active) {
                 uint32_t w0, w1, w2, w3;
                 philox4x32_10((uint32_t)(ra + rr), (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
@@ -377,12 +405,17 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 const bool acc_ = pg1_attempt(z, w0, w1, w2, w3, w);
                 if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
                     om[c] = w;
-                    c += 64; rr += qJ; j += rJ; att = 0;
-                    if (j >= J) { j -= J; ++rr; }
+                    c = (int)atomicAdd(qhead, 1u);
+                    att = 0;
                     active = c < ncell;
-                    if (active) { th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
+                    if (active) { locate(c, rr, j); th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
                 } else ++att;
             }
+        }
+        if (A.dbg_stop == 9) {
+            Ctl* cw = const_cast<Ctl*>(A.ctl);
+            atomicAdd(&cw->dbg_attempts, (unsigned long long)n_att);
+            if (lane == 0) { atomicAdd(&cw->dbg_trips, (unsigned long long)n_trip); atomicAdd(&cw->dbg_cells, (unsigned long long)ncell); }
         }
     }
     if (A.dbg_stop == 3) return;
@@ -551,7 +584,7 @@ __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
 }
 
 constexpr int TINY_THREADS = 1024;
-constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX + 8;   // LDS scratch doubles for the structural wave
+constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX + 16;   // LDS scratch doubles for the structural wave
 
 // STEP: 0 = the per-sweep step of single-pass models / CrossQr step 1; 1 = CrossQr step 2 (lambda, sig2t)
 template <int MODEL, int STEP>
@@ -643,6 +676,7 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     }
     // wave 0: beta_t (lanes cooperate through LDS)
     double* bn = work + TINY_WORK - 4 - 2 * PMAX;           // beta_t, contiguous [2p] / [p+1]
+    double* qf = work + TINY_WORK - 12 - 2 * PMAX;          // quadratic forms for Sigma_p (RtIrt)
     if (tid < 64 && STEP == 0) {
         const int lane = tid;
         if (MODEL == MLIRT) {
@@ -710,6 +744,15 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
                 if (!T.intercept && (lane == 0 || lane == p)) t = 0.0;          // src/GibbsRtIrt.pl.jl:293-295
                 bn[lane] = t;
                 beta[(lane / p) * PMAX + (lane % p)] = t;
+            }
+            wave_sync();
+            // quadratic forms needed by Sigma_p: qf[a + 2b] = beta_a' x'x beta_b, qf[4 + a + 2b] = beta_a' x'eta_b; lane f computes form f
+            if (lane < 8) {
+                const int a_ = lane & 1, b_ = (lane >> 1) & 1;
+                double v = 0.0;
+                if (lane < 4) { for (int u = 0; u < p; ++u) for (int w = 0; w < p; ++w) v += bn[a_ * p + u] * XtX[u + w * PMAX] * bn[b_ * p + w]; }
+                else { const double* xe = b_ == 0 ? G0 : G0 + p; for (int u = 0; u < p; ++u) v += bn[a_ * p + u] * xe[u]; }
+                qf[lane] = v;
             }
         } else if (MODEL == LATENTQR) {
             // getSubjCoefficientsLatentQr src/Draw.pl.jl:446-458 : beta = (x'x)^-1 x'(zeta - k1 nu), x = [1 X theta];
@@ -785,6 +828,7 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
             const double sg = invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq / 2.0);
             par[2 * J + j] = lam; par[3 * J + j] = sg;
+            part[j] = 1.0 / sg;
         }
         if (MODEL == CROSSQR && STEP == 1) {
             // lambda: drawItemIntensityCrossQr src/Draw.pl.jl:239-251 ; sig2t: drawItemTimeResidualCrossQr :278-288
@@ -799,29 +843,23 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
             const double sg = invgamma(sv, 1e-3 + Nd * 3.0 / 2.0, 1e-3 + ssq + V);
             par[2 * J + j] = lam; par[3 * J + j] = sg;
+            part[j] = 1.0 / sg;
         }
+        if (MODEL == MLIRT || (MODEL == CROSSQR && STEP == 0)) part[j] = 1.0 / par[3 * J + j];   // sig2t not drawn in this step
     }
     __syncthreads();
 
     if (T.dbg_stop == 3) return;
     // derived scalar for the row pass: sum_j 1/sig2t_j (fixed order)
-    if (tid == 64) { double t = 0.0; for (int jj = 0; jj < J; ++jj) t += 1.0 / par[3 * J + jj]; par[par_off_derived(J)] = t; }
+    if (tid == 64) { double t = 0.0; for (int jj = 0; jj < J; ++jj) t += part[jj]; par[par_off_derived(J)] = t; }   // part[j] = 1/sig2t_j (LDS)
     // =========================================================== Sigma_p_t | beta_t (thread 0; its random numbers were pre-drawn above)
     if (tid == 0 && STEP == 0 && MODEL != MLIRT) {
         double S[4] = { 1.0, 0.0, 0.0, 1.0 };
         if (MODEL == RTIRT) {
             // drawSubjCovariance src/Draw.pl.jl:499-515 : InverseWishart(N+3, e'e + I), e'e from sufficient statistics
-            const double* xt = G0, *xz = G0 + p;
+            // (the quadratic forms beta_a' x'x beta_b and beta_a' x'eta_b were reduced by wave 0 just above: qf[0..7])
             const double tt = G0[2 * p], tz = G0[2 * p + 1], zz = G0[2 * p + 2];
-            double bAb[4] = {0, 0, 0, 0}, bx[4];
-            for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) {
-                double t = 0.0;
-                for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) t += bn[a_ * p + u] * XtX[u + v * PMAX] * bn[b_ * p + v];
-                bAb[a_ + 2 * b_] = t;
-                double t2 = 0.0; const double* xe = b_ == 0 ? xt : xz;
-                for (int u = 0; u < p; ++u) t2 += bn[a_ * p + u] * xe[u];
-                bx[a_ + 2 * b_] = t2;
-            }
+            const double* bAb = qf; const double* bx = qf + 4;
             const double ee00 = tt - 2.0 * bx[0] + bAb[0];
             const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
             const double ee11 = zz - 2.0 * bx[3] + bAb[3];

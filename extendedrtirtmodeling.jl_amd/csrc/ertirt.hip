@@ -159,16 +159,11 @@ template <typename real> struct Engine : EngineBase {
             W = cfg.lanes_per_row;
             if (W > 64 || (W & (W - 1))) return fail(ERM_ERR_ARG, "lanes_per_row must be a power of two <= 64");
         } else {
-            // smallest padding waste first, then enough lanes to fill the chip (>= 4 waves per SIMD), then larger W
-            double best = 1e30; W = 8;
-            for (int w = 4; w <= 64; w <<= 1) {
-                const int ipl = (J + w - 1) / w;
-                double waste = (double)(w * ipl) / J;
-                const double lanes = (double)N * w;
-                if (lanes < 64.0 * 16 * cu_count) waste *= 1.0 + 0.25 * std::log2(64.0 * 16 * cu_count / lanes);
-                waste *= 1.0 + 0.6 / ipl;     // per-row work is amortised over ipl cell iterations
-                if (waste < best - 1e-12) { best = waste; W = w; }
-            }
+            // W only shapes the row-sum phase (the PG phase walks flattened cells): few items per lane keeps the dependent
+            // load batches short, many subjects per wave-iteration keeps the number of iterations low; W = 8 balances both
+            // for nItem around 50 (measured); never more lanes than items (rounded up to a power of two).
+            W = 8;
+            while (W > 1 && W / 2 >= J) W /= 2;
         }
         logW = 0; while ((1 << logW) < W) ++logW;
         IPL = (J + W - 1) / W;
@@ -398,6 +393,9 @@ template <typename real> struct Engine : EngineBase {
         if (hi > lo) post_rows += hi - lo;
         rows_done += nsweeps;
         sweeps_total += (uint32_t)nsweeps;
+        if (getenv("ERM_PASS_STOP") && atoi(getenv("ERM_PASS_STOP")) == 9)
+            fprintf(stderr, "[erm dbg] attempts %llu cells %llu wave-trips %llu -> attempts/cell %.4f, lane efficiency %.4f\n", back.dbg_attempts, back.dbg_cells, back.dbg_trips,
+                    (double)back.dbg_attempts / (double)back.dbg_cells, (double)back.dbg_attempts / (64.0 * (double)back.dbg_trips));
         if (back.err) {
             const int e = (int)back.err - 1;
             const char* names[] = {"a", "b", "lambda", "sig2t", "rho"};
