@@ -75,6 +75,23 @@ def cpu_baseline(model, Y, logT, X, st, sweeps):
     return dt / sweeps
 
 
+def traffic_bytes(model, N, J, args):
+    """HBM-side bytes per pass_kernel launch from the PMC counters.  Counters cannot be read from inside this process; they are
+    collected by tools/collect_profiles.sh in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this same command and
+    stored, with the gfx950 FETCH_SIZE x2 correction calibrated on a known byte count, in profiles/traffic.json.  Returned only
+    when that file describes exactly this workload; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    key = f"{model}:{N}x{J}:{args.precision}"
+    e = t.get(key)
+    return None if e is None else e.get("traffic_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,7 +189,8 @@ def main():
             algo = ALGO_BYTES[model] * cells / launches_per_sweep
             ach = algo / per_launch_s / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "kernel": "pass_kernel (fused row pass)", "launch_us": per_launch_s * 1e6,
+                               "traffic": traffic_bytes(model, N, J, args), "kernel": "pass_kernel (fused row pass)",
+                               "launch_us": per_launch_s * 1e6, "event_overhead_us": tm["event_overhead_ms"] * 1e3,
                                "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"])}
         ncpu = args.cpu_sweeps
         if ncpu != 0:

@@ -48,7 +48,7 @@ class erm_state(C.Structure):
 
 class erm_timing(C.Structure):
     _fields_ = [
-        ("run_ms", C.c_double), ("pass_ms_total", C.c_double), ("pass_launches", C.c_int64), ("sweeps", C.c_int64),
+        ("run_ms", C.c_double), ("pass_ms_total", C.c_double), ("event_overhead_ms", C.c_double), ("pass_launches", C.c_int64), ("sweeps", C.c_int64),
         ("lanes_per_row", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32), ("lds_bytes", C.c_int32),
         ("cu_count", C.c_int32), ("reserved", C.c_int32),
     ]

@@ -69,7 +69,8 @@ typedef struct {
 
 typedef struct {
     double run_ms;          /* device time of the last erm_run (HIP events on the engine's stream) */
-    double pass_ms_total;   /* sum of row-pass kernel durations in the last erm_run (profile=1), else 0 */
+    double pass_ms_total;   /* sum of row-pass kernel durations in the last erm_run (profile=1; event-pair overhead subtracted), else 0 */
+    double event_overhead_ms; /* mean duration of an empty HIP event pair on the engine's stream, measured in the same run */
     int64_t pass_launches;  /* number of row-pass launches timed */
     int64_t sweeps;         /* sweeps in the last erm_run */
     int32_t lanes_per_row, block_threads, grid_blocks, lds_bytes;

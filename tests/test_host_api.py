@@ -27,7 +27,7 @@ def test_ctypes_struct_layout_matches_header():
     assert C.sizeof(pkg._lib.erm_config) == 4 * 2 + 8 + 4 * 9 + 4 + 8 + 8 + 4 * 8     # 108 -> padded
     assert pkg._lib.erm_config.n_subj.offset == 8 and pkg._lib.erm_config.q_rt.offset == 56 and pkg._lib.erm_config.seed.offset == 64
     assert C.sizeof(pkg._lib.erm_state) == 10 * C.sizeof(C.c_void_p)
-    assert C.sizeof(pkg._lib.erm_timing) == 8 * 4 + 4 * 6
+    assert C.sizeof(pkg._lib.erm_timing) == 8 * 5 + 4 * 6
 
 
 def test_create_without_gpu_reports_an_error_instead_of_falling_back():

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's numbers are judged against (run on the GPU box from the repo root):
+#   1. --kernel-trace --stats of the default bench command            -> profiles/<tag>_kernel_stats.csv
+#   2. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (TCC slots)  -> profiles/<tag>_fetch.csv, _write.csv
+#   3. a calibration pass of FETCH_SIZE on a known byte count (row-sum phase only: exactly omega+Y+logT of the workload)
+#   4. SQ instruction / wait counters                                   -> profiles/<tag>_sq.csv
+# then tools/summarize_profiles.py turns them into profiles/traffic.json + profiles/<tag>_summary.md
+set -e
+TAG=${1:-round1}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+BENCH="python3 bench.py --steps 200 --warmup 20 --cpu-sweeps 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH --no-profile > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH --no-profile > $OUT/write.log 2>&1
+ERM_TINY_STOP=1 ERM_PASS_STOP=5 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_cal -- $BENCH --no-profile > $OUT/fetch_cal.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/sq -- $BENCH --no-profile > $OUT/sq.log 2>&1
+echo collected

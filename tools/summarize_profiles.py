@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/<tag>_*.csv, profiles/<tag>_summary.md and profiles/traffic.json."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(src, pattern))
+    return f[0] if f else None
+
+
+def counters(path, kernel="pass_kernel"):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if kernel in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v[2:]) / max(1, len(v[2:])) for k, v in agg.items()}
+
+
+stats = one("stats/*/*_kernel_stats.csv")
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats)))
+for name, pat in (("fetch", "fetch/*/*counter_collection.csv"), ("write", "write/*/*counter_collection.csv"), ("fetch_cal", "fetch_cal/*/*counter_collection.csv"), ("sq", "sq/*/*counter_collection.csv")):
+    f = one(pat)
+    if f:
+        c = counters(f)
+        json.dump(c, open(os.path.join(dst, f"{tag}_{name}_counters.json"), "w"), indent=1)
+bench = None
+for line in open(os.path.join(src, "stats.log")):
+    if line.startswith('{"metric"'):
+        bench = json.loads(line)
+fetch = json.load(open(os.path.join(dst, f"{tag}_fetch_counters.json")))["FETCH_SIZE"]
+write = json.load(open(os.path.join(dst, f"{tag}_write_counters.json")))["WRITE_SIZE"]
+cal = json.load(open(os.path.join(dst, f"{tag}_fetch_cal_counters.json")))["FETCH_SIZE"]
+wl = bench["config"]["workload"]
+N = int(wl.split("nSubj=")[1].split()[0]); J = int(wl.split("nItem=")[1].split()[0])
+known = N * J * 9.0 / 1024.0                       # KB read by the row-sum phase alone: omega 4 + Y 1 + logT 4 bytes per cell
+corr = known / cal                                 # gfx950: FETCH_SIZE under-reports coalesced streaming reads (MI355X_MICROARCH.md, HBM)
+traffic = (fetch * corr + write) * 1024.0
+key = f"rtirt:{N}x{J}:{bench['dtype']}"
+tj_path = os.path.join(dst, "traffic.json")
+tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+tj[key] = {"traffic_bytes_per_launch": traffic, "fetch_size_kb_raw": fetch, "write_size_kb": write, "fetch_correction": corr,
+           "calibration": f"row-sum phase alone (ERM_PASS_STOP=5) reads {known:.0f} KB and reports FETCH_SIZE {cal:.0f} KB", "source": f"profiles/{tag}_*"}
+json.dump(tj, open(tj_path, "w"), indent=1)
+with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
+    f.write(f"# rocprofv3 summary ({tag})\n\ncommand: `python3 bench.py --steps 200 --warmup 20 --cpu-sweeps 0`\n\n")
+    f.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
+    for r in rows[:4]:
+        f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |\n")
+    f.write(f"\nbench line of the same run: ms_per_step {bench['ms_per_step']:.4f}, roofline {json.dumps(bench.get('roofline'))}\n\n")
+    f.write(f"pass_kernel HBM-side traffic per launch: FETCH_SIZE {fetch:.0f} KB x {corr:.2f} (calibrated) + WRITE_SIZE {write:.0f} KB = {traffic/1e6:.1f} MB "
+            f"(algorithmic {13*N*J/1e6:.1f} MB)\n")
+print(open(os.path.join(dst, f"{tag}_summary.md")).read())
