@@ -64,8 +64,7 @@ template <typename real> struct PassArgs {
     double* sum_theta; double* sum_zeta; double* sum_nu;
     real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] or nullptr
     long long N; long long rows_per_block;          // each workgroup owns rows [b*rpb, (b+1)*rpb)
-    int rows_per_wave;                              // ceil(rpb / nWaves)
-    int rows_sc;                                    // subjects per wave per super-chunk (LDS staging capacity)
+    int rows_per_wave;                              // capacity of a wave's theta cache: ceil(rpb / nWaves)
     int J; int nFeat; int W; int logW; int IPL;
     int mode;             // 0 = prologue (no theta/zeta draws, no LL, no trace), 1 = full sweep pass
     uint32_t chain; uint64_t seed; double k1, k2;
@@ -101,30 +100,25 @@ constexpr int GROUP = 16;  // workgroups whose slab rows are summed by the last 
 constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Row pass.  blockDim.x = 64 * nWaves; workgroup b owns a contiguous range of subjects, wave w a balanced slice of it, walked in
-// "super-chunks" of at most rows_sc subjects so that the slice's logT/Y fit the wave's LDS staging area.  Waves are independent
-// until the epilogue (no workgroup barrier inside the loop).  Per super-chunk:
-//   stage 1  flattened, fully coalesced loads of the slice's (omega_t, Y, logT) [CrossQr pass B: (nu_t, logT)], all loads of a
-//            batch in flight; logT and Y are parked in LDS for stage 4; the per-subject sums are formed by a segmented inclusive
-//            scan across the wave (segments = subjects), tails accumulate into LDS;
-//   stage 2  one lane per subject: theta_t / zeta_t draws (LatentQr: nu_{t+1}), traces, running means, structural log-likelihood;
-//   stage 3  omega_{t+1}: persistent lanes fed by a wave-shared dynamic cell queue, one single-block PG attempt per trip;
-//   stage 4  lane = item over the wave's subjects: per-cell log-likelihood and item statistics in fp64 registers, logT/Y/theta/zeta
-//            from LDS, omega_{t+1} read back through L2 (own writes); CrossQr's per-cell nu_{t+1} draw lives here; global
-//            statistics (x'theta, ...) one per lane.
-// Epilogue: fixed-order sum of the waves' accumulators -> slab row; the last workgroup of each group reduces the group's rows.
-// HBM-side traffic per sweep is then the algorithmic minimum: one read of (omega, Y, logT), one write of omega, O(N) vectors.
+// Row pass.  blockDim.x = 64 * nWaves; workgroup b owns a contiguous range of subjects.
+//   phase 1 (lane (r, s) of a wave: subject r of the wave's group, items s, s+W, ...):
+//       row sums over omega_t / Y / logT, theta_t and zeta_t draws, per-subject outputs and global statistics, then the
+//       persistent-lane loop that draws omega_{t+1};
+//   barrier (everything the workgroup wrote for its own subjects is visible to all its waves);
+//   phase 2 (lane = item j, waves stride over the workgroup's subjects): per-cell log-likelihood terms and the item
+//       statistics, accumulated in fp64 REGISTERS with no cross-lane traffic; CrossQr's per-cell nu_{t+1} draw lives here.
+//   epilogue: fixed-order sum of the waves' accumulators -> this workgroup's slab row.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MODEL, typename real, int PHASE>
 __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(PassArgs<real> A)
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
-    const int J = A.J;
+    const int J = A.J, W = A.W, R = 64 / W, IPL = A.IPL;
     const int F = A.nFeat, p = F + 1;                // design [1 X]
     const int NG = ST::ng(p);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
-    const int RSC = A.rows_sc;                       // subjects per wave per super-chunk
+    const int s = lane & (W - 1), r = lane >> A.logW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* sh_struct = reinterpret_cast<double*>(smem);        // 8 + 2*PMAX doubles
@@ -133,13 +127,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     real* sh_item = reinterpret_cast<real*>(sh_gacc + (size_t)nWaves * NG);    // [NITEMARR][J]
     real* sh_a = sh_item, *sh_b = sh_item + J, *sh_a2 = sh_item + 2 * J, *sh_a2b = sh_item + 3 * J;
     real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
-    // per-wave areas: theta, zeta, 3 row sums (5 * RSC reals), queue head, staged logT (RSC * J reals), staged Y (RSC * J bytes)
-    const size_t wave_reals = (size_t)5 * RSC + 4 + (size_t)RSC * J;
-    real* sh_wave = sh_item + NITEMARR * J + (size_t)wave * wave_reals;
-    real* sh_th = sh_wave, *sh_ze = sh_wave + RSC, *sh_rs = sh_wave + 2 * RSC;
-    unsigned int* qhead = reinterpret_cast<unsigned int*>(sh_wave + 5 * RSC);
-    real* sh_C = sh_wave + 5 * RSC + 4;
-    uint8_t* sh_Y = reinterpret_cast<uint8_t*>(sh_item + NITEMARR * J + (size_t)nWaves * wave_reals) + (size_t)wave * RSC * J;
+    real* sh_th = sh_item + NITEMARR * J + (size_t)wave * 4 * A.rows_per_wave;   // theta_t of this wave's subjects
+    real* sh_rs = sh_th + A.rows_per_wave;                                         // [rows_per_wave][3] row sums
 
     const uint8_t* __restrict__ gY = A.Y;
     const real* __restrict__ gC = A.C;
@@ -162,7 +151,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         else if (threadIdx.x == 4) v = A.par[par_off_derived(J)];                // sum_j 1/sig2t_j
         sh_struct[threadIdx.x] = v;
     }
-    for (int e = threadIdx.x; e < nWaves * (NSTAT * J + NG); e += blockDim.x) sh_acc[e] = 0.0;
+    for (int e = threadIdx.x; e < nWaves * NG; e += blockDim.x) sh_gacc[e] = 0.0;
     __syncthreads();
 
     const real sig11 = (MODEL == MLIRT) ? real(1) : (real)sh_struct[0];
@@ -180,347 +169,349 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
 
     const long long row0 = (long long)blockIdx.x * A.rows_per_block;
     const long long row1 = (row0 + A.rows_per_block < A.N) ? row0 + A.rows_per_block : A.N;
-    // wave w owns a contiguous, balanced slice [wa, wb) of the workgroup's subjects
+    // wave w owns a contiguous, balanced slice [ra, rb) of the workgroup's subjects
     const int nrows_blk = (int)(row1 - row0);
     const int rbase = nrows_blk / nWaves, rrem = nrows_blk % nWaves;
-    const long long wa = row0 + (long long)wave * rbase + (wave < rrem ? wave : rrem);
-    const long long wb = wa + rbase + (wave < rrem ? 1 : 0);
-    const float invJ = 1.0f / (float)J;
-    auto locate = [&](int c, int& rr, int& j) {      // flattened cell c of a super-chunk -> (subject within it, item); exact for c < 2^22
-        rr = (int)(((float)c + 0.5f) * invJ);
-        j = c - rr * J;
-        if (j < 0) { j += J; --rr; } else if (j >= J) { j -= J; ++rr; }
-    };
+    const long long ra = row0 + (long long)wave * rbase + (wave < rrem ? wave : rrem);
+    const long long rb = ra + rbase + (wave < rrem ? 1 : 0);
     if (A.dbg_stop == 1) return;
 
-    for (long long ra = wa; ra < wb; ra += RSC) {
-        const long long rb = (ra + RSC < wb) ? ra + RSC : wb;
-        const int nrow = (int)(rb - ra);
-        const int ncell = nrow * J;
-        const size_t cell0 = (size_t)ra * J;
-
-        // ============================================================================================ stage 1
-        // lane (r, s): subject r of a group of R = 64/W, items s, s+W, ...; batches of KB items per lane with every load issued
-        // before any use (clamped index + mask: no branches); logT / Y are parked in LDS for stage 4 on the way
-        {
-            const int W = A.W, R = 64 / W, IPL = A.IPL;
-            const int s_ = lane & (W - 1), r_ = lane >> A.logW;
-            for (int g0 = 0; g0 < nrow; g0 += R) {
-                const int li = g0 + r_;
-                const bool rowok = li < nrow;
-                const int lic = rowok ? li : 0;
-                const size_t base = cell0 + (size_t)lic * J;
-                real s0 = 0, s1 = 0, s2 = 0;
-                const real thr = (PHASE == 1) ? A.theta[ra + lic] : real(0);
-                for (int k0 = 0; k0 < IPL; k0 += KB) {
-                    real wv[KB], cv[KB]; uint8_t yv[KB]; int jv4[KB]; bool ok4[KB];
+    // =================================================================================================== phase 1 (i)
+    // sums over each subject's items; lane (r, s): subject r of the group, items s, s+W, ...
+    if (A.mode == 1) {
+        for (long long g0 = ra; g0 < rb; g0 += R) {
+            const long long i = g0 + r;
+            const bool rowok = i < rb;
+            const size_t base = (size_t)(rowok ? i : ra) * J;
+            real s0 = 0, s1 = 0, s2 = 0;
+            // batches of 4 items per lane with every load issued before any use (clamped index + mask: no branches)
+            const real thr = (PHASE == 1 && rowok) ? A.theta[i] : real(0);
+            for (int k0 = 0; k0 < IPL; k0 += KB) {
+                real wv[KB], cv[KB], yv[KB]; int jv4[KB]; bool ok4[KB];
 #pragma unroll
-                    for (int u = 0; u < KB; ++u) {
-                        const int j = s_ + W * (k0 + u);
-                        ok4[u] = rowok && (k0 + u) < IPL && j < J;
-                        jv4[u] = ok4[u] ? j : 0;
-                        const size_t e = base + jv4[u];
-                        wv[u] = (PHASE == 0) ? A.omega[e] : A.nu[e];
-                        yv[u] = (PHASE == 0) ? gY[e] : (uint8_t)0;
-                        cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
-                    }
+                for (int u = 0; u < KB; ++u) {
+                    const int j = s + W * (k0 + u);
+                    ok4[u] = rowok && (k0 + u) < IPL && j < J;
+                    jv4[u] = ok4[u] ? j : 0;
+                    const size_t e = base + jv4[u];
+                    wv[u] = (PHASE == 0) ? A.omega[e] : A.nu[e];
+                    yv[u] = (PHASE == 0) ? (real)gY[e] : real(0);
+                    cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
+                }
 #pragma unroll
-                    for (int u = 0; u < KB; ++u) {
-                        const int j = jv4[u];
-                        if (ok4[u]) { if (MODEL != MLIRT) sh_C[lic * J + j] = cv[u]; if (PHASE == 0) sh_Y[lic * J + j] = yv[u]; }
-                        const real m = ok4[u] ? real(1) : real(0);
-                        if (PHASE == 0) {
-                            const real kap = (real)yv[u] - real(0.5);
-                            s0 += m * (sh_a2[j] * wv[u]);
-                            s1 += m * (sh_a[j] * kap + sh_a2b[j] * wv[u]);
-                            if (MODEL == RTIRT || MODEL == LATENTQR) s2 += m * ((sh_lamc[j] - cv[u]) * sh_isig[j]);
-                        } else {   // CrossQr pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202); theta_t is final
-                            const real nu = ok4[u] ? wv[u] : real(1);
-                            const real iden = r_div(sh_isig[j], k2 * nu);
-                            s0 += m * iden;
-                            s2 += m * ((sh_lamc[j] - cv[u] - thr * sh_rho[j] + k1 * nu) * iden);
-                        }
-                    }
-                }
-                if (A.mode == 1) {
-                    s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W);
-                    if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
-                    if (rowok && s_ == 0) { sh_rs[3 * li] = s0; sh_rs[3 * li + 1] = s1; sh_rs[3 * li + 2] = s2; }
-                }
-            }
-        }
-        wave_sync();
-        if (A.dbg_stop == 5) continue;
-
-        // ============================================================================================ stage 2
-        for (int ib = 0; ib < nrow; ib += 64) {
-            const bool rok = ib + lane < nrow;
-            const int li = rok ? ib + lane : 0;                  // clamped: loads are unconditional, stores masked
-            const long long i = ra + li;
-            real th = A.theta[i];
-            real ze = (MODEL != MLIRT) ? A.zeta[i] : real(0);
-            real nu_row = real(1);
-            if (MODEL == LATENTQR) nu_row = A.nu[i];
-            real mu0a = 0, mu0b = 0;
-            if (PHASE == 0 && MODEL != CROSSQR) {
-                for (int u = 0; u < p; ++u) {
-                    const real xu = (u == 0) ? real(1) : gX[(size_t)i * F + (u - 1)];
-                    mu0a += xu * (real)beta[u];
-                    if (MODEL == RTIRT) mu0b += xu * (real)beta[PMAX + u];
-                }
-            }
-            real xb5 = 0;
-            if (A.mode == 1) {
-                const real sA = sh_rs[3 * li], sB = sh_rs[3 * li + 1], sC = sh_rs[3 * li + 2];
-                // one Philox block per subject and sweep feeds both row draws: words 0,1 -> theta's normal, words 2,3 -> zeta's
-                uint32_t rw0, rw1, rw2, rw3;
-                philox4x32_10((uint32_t)i, 0u, sweep, ((uint32_t)SITE_THETA << 24) | ((A.chain & 0xFFu) << 16), (uint32_t)A.seed, (uint32_t)(A.seed >> 32), rw0, rw1, rw2, rw3);
-                if (PHASE == 0) {
-                    // theta: src/Draw.pl.jl:49-62 (prior x*beta[:,1]) / :67-80 (Null prior)
-                    const real mu0 = (MODEL == MLIRT || MODEL == RTIRT) ? mu0a : real(0);
-                    const real parV = r_rcp(r_rcp(sig11) + sA);
-                    const real parM = parV * (r_div(mu0, sig11) + sB);
-                    th = parM + r_sqrt(parV) * row_normal<real>(rw0, rw1);
-                }
-                if (MODEL == RTIRT || MODEL == LATENTQR) {
-                    // zeta: src/Draw.pl.jl:132-141 / :161-174
-                    real mu0 = mu0b, s0 = sig22;
-                    if (MODEL == LATENTQR) {
-                        xb5 = mu0a + th * (real)beta[p];
-                        mu0 = xb5 + k1 * nu_row;
-                        s0 = sig22 * (k2 * nu_row);
-                    }
-                    const real parV = r_rcp(r_rcp(s0) + sum_isig);
-                    const real parM = parV * (r_div(mu0, s0) + sC);
-                    ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
-                }
-                if (MODEL == CROSSQR && PHASE == 1) {
-                    // zeta: src/Draw.pl.jl:192-206 (zero prior mean, prior variance Sigp[2,2]); sA = sum of weights here
-                    const real parV = r_rcp(r_rcp(sig22) + sA);
-                    const real parM = parV * sC;
-                    ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
-                }
-                if (rok) {
+                for (int u = 0; u < KB; ++u) {
+                    const int j = jv4[u];
+                    const real m = ok4[u] ? real(1) : real(0);
                     if (PHASE == 0) {
-                        A.theta[i] = th;
-                        if (A.tr_theta) A.tr_theta[(size_t)trow * A.N + i] = th;
-                        if (post_burn) A.sum_theta[i] += (double)th;
-                    }
-                    if ((MODEL == RTIRT || MODEL == LATENTQR) || (MODEL == CROSSQR && PHASE == 1)) {
-                        A.zeta[i] = ze;
-                        if (A.tr_zeta) A.tr_zeta[(size_t)trow * A.N + i] = ze;
-                        if (post_burn) A.sum_zeta[i] += (double)ze;
-                    }
-                    // structural log-likelihood terms (src/GibbsRtIrt.pl.jl:201,269; src/GibbsRtIrtLatent.pl.jl:261)
-                    if (MODEL == MLIRT) {
-                        const real e = th - mu0a;
-                        ll += -0.5 * LOG_2PI - 0.5 * (double)(e * e);
-                    } else if (MODEL == RTIRT || (MODEL == CROSSQR && PHASE == 1)) {
-                        const double e0 = (double)(th - mu0a), e1 = (double)(ze - mu0b);
-                        ll += sp_c0 - 0.5 * (sp_q00 * e0 * e0 + sp_q01 * e0 * e1 + sp_q11 * e1 * e1);
-                    } else if (MODEL == LATENTQR) {
-                        const double var = (double)sig22 * ((double)k2 * (double)nu_row);
-                        const double e = (double)(ze - (xb5 + k1 * nu_row));
-                        ll += -0.5 * LOG_2PI - 0.5 * log(var) - 0.5 * e * e / var;
-                        if (A.tr_nu) A.tr_nu[(size_t)trow * A.N + i] = nu_row;
-                        if (post_burn) A.sum_nu[i] += (double)nu_row;
-                    }
-                }
-            } else if (MODEL == LATENTQR) {
-                xb5 = mu0a + th * (real)beta[p];
-            }
-            if (MODEL == LATENTQR) {
-                // nu_{t+1}: src/Draw.pl.jl:325-343 (depends on zeta_t, theta_t, beta_t, Sigp_t only)
-                const real den = r_sqrt(sig22 * k2);
-                const real parA = r_div(r_abs(ze - xb5), den);
-                const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
-                Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, 0u, sweep + 1u);
-                const real nu_next = qr_weight<real>(st, parA, parB);
-                if (rok) A.nu[i] = nu_next;
-            }
-            if (rok) { sh_th[li] = th; sh_ze[li] = ze; }
-        }
-        wave_sync();
-        if (A.dbg_stop == 2) continue;
-
-        // ============================================================================================ stage 3
-        // omega_{t+1} | theta_t, a_t, b_t (src/Draw.pl.jl:36-40).  Cells are handed out dynamically from a wave-shared LDS counter:
-        // a lane that finishes a cell grabs the next index, so every lane stays busy until the slice is exhausted (which lane
-        // draws which cell does not matter: draws are addressed by (i, j, sweep), never by lane).  Each trip makes ONE
-        // single-block PG attempt; attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
-        if constexpr (PHASE == 0) {
-            if (lane == 0) *qhead = 64u;
-            wave_sync();
-            int c = lane, rr, j;
-            locate(c, rr, j);
-            bool active = c < ncell;
-            uint32_t att = 0;
-            real th = active ? sh_th[rr] : real(0);
-            real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
-            real* om = A.omega + cell0;
-            const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
-            unsigned int n_att = 0, n_trip = 0;
-            while (__any(active)) {
-                ++n_trip; n_att += active ? 1u : 0u;
-                if (active) {
-                    uint32_t w0, w1, w2, w3;
-                    philox4x32_10((uint32_t)(ra + rr), (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
-                    real w;
-                    const bool acc_ = pg1_attempt(z, w0, w1, w2, w3, w);
-                    if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
-                        om[c] = w;
-                        c = (int)atomicAdd(qhead, 1u);
-                        att = 0;
-                        active = c < ncell;
-                        if (active) { locate(c, rr, j); th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
-                    } else ++att;
-                }
-            }
-            if (A.dbg_stop == 9) {
-                Ctl* cw = const_cast<Ctl*>(A.ctl);
-                atomicAdd(&cw->dbg_attempts, (unsigned long long)n_att);
-                if (lane == 0) { atomicAdd(&cw->dbg_trips, (unsigned long long)n_trip); atomicAdd(&cw->dbg_cells, (unsigned long long)ncell); }
-            }
-            __threadfence_block();                              // this wave's omega stores are complete before it reads them back
-        }
-        if (A.dbg_stop == 3) continue;
-
-        // ============================================================================================ stage 4
-        // lane = item j over the wave's subjects of this super-chunk; accumulators in fp64 registers, flushed to the wave's LDS slots
-        for (int cb = 0; cb * 64 < J; ++cb) {
-            const int j = cb * 64 + lane;
-            const bool jv = j < J;
-            const int jc = jv ? j : 0;
-            const real a = sh_a[jc], b = sh_b[jc], lamc = sh_lamc[jc], isig = sh_isig[jc], lsig = sh_lsig[jc], rho = sh_rho[jc];
-            double S[NSTAT];
-#pragma unroll
-            for (int q = 0; q < NSTAT; ++q) S[q] = 0.0;
-            double llc = 0.0;
-            for (int r0 = 0; r0 < nrow; r0 += 4) {
-                real wv[4], nv[4]; bool okv[4]; int rv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {                   // global loads of the batch first
-                    rv[u] = (r0 + u < nrow) ? r0 + u : nrow - 1;
-                    okv[u] = jv && (r0 + u < nrow);
-                    const size_t e = cell0 + (size_t)rv[u] * J + jc;
-                    wv[u] = (PHASE == 0) ? A.omega[e] : real(0);
-                    nv[u] = (MODEL == CROSSQR) ? A.nu[e] : real(1);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!okv[u]) continue;
-                    const int li = rv[u];
-                    const long long i = ra + li;
-                    const size_t e = cell0 + (size_t)li * J + j;
-                    const real th = (PHASE == 0) ? sh_th[li] : A.theta[i];
-                    const real ze = sh_ze[li];
-                    const real c = (MODEL != MLIRT) ? sh_C[li * J + j] : real(0);
-                    if constexpr (PHASE == 0) {
-                        const real w = wv[u];
-                        const bool y = sh_Y[li * J + j] != 0;
-                        const double wd = (double)w, thd = (double)th;
-                        S[0] += wd; S[1] += wd * thd; S[2] += wd * thd * thd; S[3] += y ? 0.5 * thd : -0.5 * thd;
-                        if constexpr (MODEL == RTIRT || MODEL == LATENTQR) S[4] += (double)c * (double)ze;
-                        if (A.mode == 1) {
-                            const real eta = a * (th - b);
-                            real t = (y ? eta : real(0)) - log1pexp_r(eta);
-                            if (MODEL == RTIRT || MODEL == LATENTQR) {
-                                const real er = c + ze - lamc;
-                                t += real(-0.5) * ((real)LOG_2PI + lsig + er * er * isig);
-                            }
-                            llc += (double)t;
-                        }
-                        if constexpr (MODEL == CROSSQR) {
-                            // statistics for lambda_t, sig2t_t (src/Draw.pl.jl:246-247, 285) with nu_t, zeta_{t-1}, theta_t, rho_t
-                            const real nu = nv[u];
-                            const real rr_ = c + ze + th * rho - k1 * nu;
-                            const double inu = 1.0 / (double)nu, rd = (double)rr_;
-                            S[4] += inu; S[5] += rd * inu; S[6] += rd * rd * inu; S[7] += (double)nu;
-                        }
-                    } else {
-                        // CrossQr pass B: RT log-likelihood with nu_t, then nu_{t+1} (src/Draw.pl.jl:303-320) and rho statistics (:484-485)
-                        const real nu = nv[u];
-                        if (A.mode == 1) {
-                            const real var_ = k2 * nu;                               // times sig2t_j
-                            const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
-                            llc += (double)(real(-0.5) * ((real)LOG_2PI + lsig + r_log(var_) + r_div(er * er * isig, var_)));
-                            if (post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
-                        }
-                        const real den = r_div(r_sqrt(k2), r_sqrt(isig));            // sqrt(sig2t k2)
-                        const real parA = r_div(r_abs(c - lamc + ze + th * rho), den);
-                        const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
-                        Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, (uint32_t)j, sweep + 1u);
-                        const real nun = qr_weight<real>(st, parA, parB);
-                        A.nu[e] = nun;
-                        const double inu = 1.0 / (double)nun, thd = (double)th;
-                        S[0] += thd * thd * inu;
-                        S[1] += thd * (double)(lamc - ze - c + k1 * nun) * inu;
+                        const real kap = yv[u] - real(0.5);
+                        s0 += m * (sh_a2[j] * wv[u]);
+                        s1 += m * (sh_a[j] * kap + sh_a2b[j] * wv[u]);
+                        if (MODEL == RTIRT || MODEL == LATENTQR) s2 += m * ((sh_lamc[j] - cv[u]) * sh_isig[j]);
+                    } else {   // CrossQr pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202)
+                        const real nu = ok4[u] ? wv[u] : real(1);
+                        const real iden = r_div(sh_isig[j], k2 * nu);
+                        s0 += m * iden;
+                        s2 += m * ((sh_lamc[j] - cv[u] - thr * sh_rho[j] + k1 * nu) * iden);
                     }
                 }
             }
-            if (jv) {
-#pragma unroll
-                for (int q = 0; q < NSTAT; ++q) acc[q * J + j] += S[q];
-            }
-            ll += llc;
+            s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W);
+            if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
+            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - ra); o[0] = s0; o[1] = s1; o[2] = s2; }
         }
-
-        // ---- global statistics for the next tiny step: lane g accumulates ONE sum over subjects of a product of two per-subject
-        // values.  value codes: 0 -> 1, 1..F -> X columns, F+1 theta, F+2 zeta, F+3 u = zeta - k1 nu_{t+1}, F+4 nu_{t+1}
-        if (NG > 1 && lane < NG - 1) {
-            const int cT = F + 1, cZ = F + 2, cU = F + 3, cN = F + 4;
-            const int g = lane;
-            int ca = 0, cb2 = 0;
-            if (MODEL == MLIRT) { ca = g; cb2 = cT; }
-            else if (MODEL == RTIRT) {
-                if (g < p) { ca = g; cb2 = cT; }
-                else if (g < 2 * p) { ca = g - p; cb2 = cZ; }
-                else if (g == 2 * p) { ca = cT; cb2 = cT; }
-                else if (g == 2 * p + 1) { ca = cT; cb2 = cZ; }
-                else { ca = cZ; cb2 = cZ; }
-            } else if (MODEL == LATENTQR) {
-                if (g < p) { ca = g; cb2 = cT; }
-                else if (g == p) { ca = cT; cb2 = cT; }
-                else if (g < 2 * p + 1) { ca = g - p - 1; cb2 = cU; }
-                else if (g == 2 * p + 1) { ca = cT; cb2 = cU; }
-                else if (g == 2 * p + 2) { ca = cU; cb2 = cU; }
-                else if (g == 2 * p + 3) { ca = 0; cb2 = cN; }
-                else if (g == 2 * p + 4) { ca = cN; cb2 = cN; }
-                else if (g == 2 * p + 5) { ca = 0; cb2 = cZ; }
-                else { ca = cZ; cb2 = cZ; }
-            } else { ca = cZ; cb2 = cZ; }      // CrossQr pass B: sum zeta^2
-            const int xa = (ca >= 1 && ca <= F) ? ca - 1 : 0, xb = (cb2 >= 1 && cb2 <= F) ? cb2 - 1 : 0;
-            double gsum = 0.0;
-            for (int r0 = 0; r0 < nrow; r0 += 4) {
-                double xva[4], xvb[4], nuv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const long long i = ra + ((r0 + u < nrow) ? r0 + u : nrow - 1);
-                    xva[u] = F > 0 ? (double)gX[(size_t)i * F + xa] : 0.0;
-                    xvb[u] = F > 0 ? (double)gX[(size_t)i * F + xb] : 0.0;
-                    nuv[u] = (MODEL == LATENTQR) ? (double)A.nu[i] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (r0 + u >= nrow) continue;
-                    const int li = r0 + u;
-                    const double th = (PHASE == 0) ? (double)sh_th[li] : (double)A.theta[ra + li];
-                    const double ze = (double)sh_ze[li];
-                    const double up = ze - (double)k1 * nuv[u];
-                    const double va = ca == 0 ? 1.0 : (ca <= F ? xva[u] : (ca == cT ? th : (ca == cZ ? ze : (ca == cU ? up : nuv[u]))));
-                    const double vb = cb2 == 0 ? 1.0 : (cb2 <= F ? xvb[u] : (cb2 == cT ? th : (cb2 == cZ ? ze : (cb2 == cU ? up : nuv[u]))));
-                    gsum += va * vb;
-                }
-            }
-            gtot[g] += gsum;
-        }
-        wave_sync();                                            // the per-wave LDS areas are reused by the next super-chunk
     }
+    wave_sync();
+    if (A.dbg_stop == 5) return;
+
+    // =================================================================================================== phase 1 (ii)
+    // one lane per subject: theta_t / zeta_t draws, per-subject outputs, structural log-likelihood, LatentQr's nu_{t+1}
+    for (long long ib = ra; ib < rb; ib += 64) {
+        const bool rok = ib + lane < rb;
+        const long long i = rok ? ib + lane : ra;          // clamped: loads are unconditional, stores masked
+        const int li = (int)(i - ra);
+        real th = A.theta[i];
+        real ze = (MODEL != MLIRT) ? A.zeta[i] : real(0);
+        real nu_row = real(1);
+        if (MODEL == LATENTQR) nu_row = A.nu[i];
+        real mu0a = 0, mu0b = 0;
+        real xr[8];                                         // first 8 covariates of the subject, loaded once (all loads up front)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xr[u] = (PHASE == 0 && MODEL != CROSSQR && u < F) ? gX[(size_t)i * F + u] : real(0);
+        auto xcol = [&](int u) -> real {                    // column u of [1 X]
+            if (u == 0) return real(1);
+            real v = real(0);
+            if (u <= 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v = (q == u - 1) ? xr[q] : v;
+                return v;
+            }
+            return gX[(size_t)i * F + (u - 1)];
+        };
+        if (PHASE == 0 && MODEL != CROSSQR) {
+            for (int u = 0; u < p; ++u) {
+                const real xu = xcol(u);
+                mu0a += xu * (real)beta[u];
+                if (MODEL == RTIRT) mu0b += xu * (real)beta[PMAX + u];
+            }
+        }
+        real xb5 = 0, nu_next = real(0);
+        if (A.mode == 1) {
+            const real sA = sh_rs[3 * li], sB = sh_rs[3 * li + 1], sC = sh_rs[3 * li + 2];
+            // one Philox block per subject and sweep feeds both row draws: words 0,1 -> theta's normal, words 2,3 -> zeta's
+            uint32_t rw0, rw1, rw2, rw3;
+            philox4x32_10((uint32_t)i, 0u, sweep, ((uint32_t)SITE_THETA << 24) | ((A.chain & 0xFFu) << 16), (uint32_t)A.seed, (uint32_t)(A.seed >> 32), rw0, rw1, rw2, rw3);
+            if (PHASE == 0) {
+                // theta: src/Draw.pl.jl:49-62 (prior x*beta[:,1]) / :67-80 (Null prior)
+                const real mu0 = (MODEL == MLIRT || MODEL == RTIRT) ? mu0a : real(0);
+                const real parV = r_rcp(r_rcp(sig11) + sA);
+                const real parM = parV * (r_div(mu0, sig11) + sB);
+                th = parM + r_sqrt(parV) * row_normal<real>(rw0, rw1);
+            }
+            if (MODEL == RTIRT || MODEL == LATENTQR) {
+                // zeta: src/Draw.pl.jl:132-141 / :161-174
+                real mu0 = mu0b, s0 = sig22;
+                if (MODEL == LATENTQR) {
+                    xb5 = mu0a + th * (real)beta[p];
+                    mu0 = xb5 + k1 * nu_row;
+                    s0 = sig22 * (k2 * nu_row);
+                }
+                const real parV = r_rcp(r_rcp(s0) + sum_isig);
+                const real parM = parV * (r_div(mu0, s0) + sC);
+                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
+            }
+            if (MODEL == CROSSQR && PHASE == 1) {
+                // zeta: src/Draw.pl.jl:192-206 (zero prior mean, prior variance Sigp[2,2]); sA = sum of weights here
+                const real parV = r_rcp(r_rcp(sig22) + sA);
+                const real parM = parV * sC;
+                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
+            }
+            if (rok) {
+                if (PHASE == 0) {
+                    A.theta[i] = th;
+                    if (A.tr_theta) A.tr_theta[(size_t)trow * A.N + i] = th;
+                    if (post_burn) A.sum_theta[i] += (double)th;
+                }
+                if ((MODEL == RTIRT || MODEL == LATENTQR) || (MODEL == CROSSQR && PHASE == 1)) {
+                    A.zeta[i] = ze;
+                    if (A.tr_zeta) A.tr_zeta[(size_t)trow * A.N + i] = ze;
+                    if (post_burn) A.sum_zeta[i] += (double)ze;
+                }
+                // structural log-likelihood terms (src/GibbsRtIrt.pl.jl:201,269; src/GibbsRtIrtLatent.pl.jl:261)
+                if (MODEL == MLIRT) {
+                    const real e = th - mu0a;
+                    ll += -0.5 * LOG_2PI - 0.5 * (double)(e * e);
+                } else if (MODEL == RTIRT || (MODEL == CROSSQR && PHASE == 1)) {
+                    const double e0 = (double)(th - mu0a), e1 = (double)(ze - mu0b);
+                    ll += sp_c0 - 0.5 * (sp_q00 * e0 * e0 + sp_q01 * e0 * e1 + sp_q11 * e1 * e1);
+                } else if (MODEL == LATENTQR) {
+                    const double var = (double)sig22 * ((double)k2 * (double)nu_row);
+                    const double e = (double)(ze - (xb5 + k1 * nu_row));
+                    ll += -0.5 * LOG_2PI - 0.5 * log(var) - 0.5 * e * e / var;
+                    if (A.tr_nu) A.tr_nu[(size_t)trow * A.N + i] = nu_row;
+                    if (post_burn) A.sum_nu[i] += (double)nu_row;
+                }
+            }
+        } else if (MODEL == LATENTQR) {
+            xb5 = mu0a + th * (real)beta[p];
+        }
+        if (MODEL == LATENTQR) {
+            // nu_{t+1}: src/Draw.pl.jl:325-343 (depends on zeta_t, theta_t, beta_t, Sigp_t only)
+            const real den = r_sqrt(sig22 * k2);
+            const real parA = r_div(r_abs(ze - xb5), den);
+            const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
+            Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, 0u, sweep + 1u);
+            nu_next = qr_weight<real>(st, parA, parB);
+            if (rok) A.nu[i] = nu_next;
+        }
+        if (PHASE == 0 && rok) sh_th[li] = th;
+
+        // ---- global statistics for the next tiny step: each is a sum over subjects of a product of two per-subject values;
+        // summed over the 64 subjects of this trip by a wave butterfly (fixed order), then accumulated by lane 0.
+        // value codes: 0 -> 1, 1..F -> X columns, F+1 theta, F+2 zeta, F+3 u = zeta - k1 nu_{t+1}, F+4 nu_{t+1}
+        if (NG > 1) {
+            const int cT = F + 1, cZ = F + 2, cU = F + 3, cN = F + 4;
+            const double thd = (double)th, zed = (double)ze, nud = (double)nu_next, upd = zed - (double)k1 * nud;
+            auto val = [&](int code) -> double {
+                if (code == 0) return 1.0;
+                if (code <= F) return (double)xcol(code);
+                if (code == cT) return thd;
+                if (code == cZ) return zed;
+                if (code == cU) return upd;
+                return nud;
+            };
+            for (int g = 0; g < NG - 1; ++g) {
+                int ca = 0, cb2 = 0;
+                if (MODEL == MLIRT) { ca = g; cb2 = cT; }
+                else if (MODEL == RTIRT) {
+                    if (g < p) { ca = g; cb2 = cT; }
+                    else if (g < 2 * p) { ca = g - p; cb2 = cZ; }
+                    else if (g == 2 * p) { ca = cT; cb2 = cT; }
+                    else if (g == 2 * p + 1) { ca = cT; cb2 = cZ; }
+                    else { ca = cZ; cb2 = cZ; }
+                } else if (MODEL == LATENTQR) {
+                    if (g < p) { ca = g; cb2 = cT; }
+                    else if (g == p) { ca = cT; cb2 = cT; }
+                    else if (g < 2 * p + 1) { ca = g - p - 1; cb2 = cU; }
+                    else if (g == 2 * p + 1) { ca = cT; cb2 = cU; }
+                    else if (g == 2 * p + 2) { ca = cU; cb2 = cU; }
+                    else if (g == 2 * p + 3) { ca = 0; cb2 = cN; }
+                    else if (g == 2 * p + 4) { ca = cN; cb2 = cN; }
+                    else if (g == 2 * p + 5) { ca = 0; cb2 = cZ; }
+                    else { ca = cZ; cb2 = cZ; }
+                } else { ca = cZ; cb2 = cZ; }      // CrossQr pass B: sum zeta^2
+                double v = rok ? val(ca) * val(cb2) : 0.0;
+                v = bfly_sum(v, 1, 64);
+                if (lane == 0) gtot[g] += v;
+            }
+        }
+    }
+    if (A.dbg_stop == 2) return;
+
+    // ---------------- omega_{t+1} | theta_t, a_t, b_t  (src/Draw.pl.jl:36-40), persistent lanes over the wave's flattened cells:
+    // lane l owns cells l, l+64, l+128, ... of the slice (cell c = (subject ra + c / J, item c % J), which is also its offset in
+    // the row-major omega slice, so stores are fully coalesced).  Each trip makes ONE single-block PG attempt; a lane moves on
+    // to its next cell as soon as a draw is accepted, so a wave pays the max over lanes of the TOTAL attempts of ~equal queues.
+    // Attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
+    if constexpr (PHASE == 0) {
+        wave_sync();                                  // sh_th written above
+        const int ncell = (int)(rb - ra) * J;
+        const float invJ = 1.0f / (float)J;
+        // cells are handed out dynamically from a wave-shared LDS counter: a lane that finishes a cell grabs the next index, so
+        // every lane stays busy until the slice is exhausted (which lane draws which cell does not matter: draws are addressed
+        // by (i, j, sweep), never by lane)
+        unsigned int* qhead = reinterpret_cast<unsigned int*>(sh_rs);      // the row sums are dead by now
+        if (lane == 0) *qhead = 64u;
+        wave_sync();
+        auto locate = [&](int c, int& rr, int& j) {      // c -> (row within slice, item); exact for c < 2^22
+            rr = (int)(((float)c + 0.5f) * invJ);
+            j = c - rr * J;
+            if (j < 0) { j += J; --rr; } else if (j >= J) { j -= J; ++rr; }
+        };
+        int c = lane, rr, j;
+        locate(c, rr, j);
+        bool active = c < ncell;
+        uint32_t att = 0;
+        real th = active ? sh_th[rr] : real(0);
+        real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
+        real* om = A.omega + (size_t)ra * J;
+        const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
+        unsigned int n_att = 0, n_trip = 0;
+        while (__any(active)) {
+            ++n_trip; n_att += active ? 1u : 0u;
+            if (active) {
+                uint32_t w0, w1, w2, w3;
+                philox4x32_10((uint32_t)(ra + rr), (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                real w;
+                const bool acc_ = pg1_attempt(z, w0, w1, w2, w3, w);
+                if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
+                    om[c] = w;
+                    c = (int)atomicAdd(qhead, 1u);
+                    att = 0;
+                    active = c < ncell;
+                    if (active) { locate(c, rr, j); th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
+                } else ++att;
+            }
+        }
+        if (A.dbg_stop == 9) {
+            Ctl* cw = const_cast<Ctl*>(A.ctl);
+            atomicAdd(&cw->dbg_attempts, (unsigned long long)n_att);
+            if (lane == 0) { atomicAdd(&cw->dbg_trips, (unsigned long long)n_trip); atomicAdd(&cw->dbg_cells, (unsigned long long)ncell); }
+        }
+    }
+    if (A.dbg_stop == 3) return;
+    __syncthreads();
+
+    // =================================================================================================== phase 2
+    // lane = item j; the waves stride over the workgroup's subjects; accumulators live in fp64 registers
+    for (int cb = 0; cb * 64 < J && A.dbg_stop != 7; ++cb) {
+        const int j = cb * 64 + lane;
+        const bool jv = j < J;
+        const real a = jv ? sh_a[j] : real(0), b = jv ? sh_b[j] : real(0);
+        const real lamc = jv ? sh_lamc[j] : real(0), isig = jv ? sh_isig[j] : real(1), lsig = jv ? sh_lsig[j] : real(0);
+        const real rho = jv ? sh_rho[j] : real(0);
+        double S[NSTAT];
+#pragma unroll
+        for (int q = 0; q < NSTAT; ++q) S[q] = 0.0;
+        double llc = 0.0;
+        const int jc = jv ? j : 0;
+        for (long long i0 = row0 + wave; i0 < row1; i0 += 4LL * nWaves) {
+            real thv[4], zev[4], wv[4], cv[4], nv[4]; bool yv[4], okv[4]; long long iv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                 // every load of the batch is issued before any use
+                const long long i = i0 + (long long)u * nWaves;
+                okv[u] = jv && i < row1;
+                iv[u] = i < row1 ? i : row1 - 1;
+                const size_t e = (size_t)iv[u] * J + jc;
+                thv[u] = A.theta[iv[u]];
+                zev[u] = (MODEL != MLIRT) ? A.zeta[iv[u]] : real(0);
+                wv[u] = (PHASE == 0) ? A.omega[e] : real(0);
+                yv[u] = (PHASE == 0) ? (gY[e] != 0) : false;
+                cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
+                nv[u] = (MODEL == CROSSQR) ? A.nu[e] : real(1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!okv[u]) continue;
+                const long long i = iv[u];
+                const size_t e = (size_t)i * J + j;
+                const real th = thv[u], ze = zev[u];
+                if constexpr (PHASE == 0) {
+                    const real w = wv[u];
+                    const bool y = yv[u];
+                    const real c = cv[u];
+                    const double wd = (double)w, thd = (double)th;
+                    S[0] += wd; S[1] += wd * thd; S[2] += wd * thd * thd; S[3] += y ? 0.5 * thd : -0.5 * thd;
+                    if constexpr (MODEL == RTIRT || MODEL == LATENTQR) S[4] += (double)c * (double)ze;
+                    if (A.mode == 1) {
+                        const real eta = a * (th - b);
+                        real t = (y ? eta : real(0)) - log1pexp_r(eta);
+                        if (MODEL == RTIRT || MODEL == LATENTQR) {
+                            const real er = c + ze - lamc;
+                            t += real(-0.5) * ((real)LOG_2PI + lsig + er * er * isig);
+                        }
+                        llc += (double)t;
+                    }
+                    if constexpr (MODEL == CROSSQR) {
+                        // statistics for lambda_t, sig2t_t (src/Draw.pl.jl:246-247, 285) with nu_t, zeta_{t-1}, theta_t, rho_t
+                        const real nu = nv[u];
+                        const real rr = c + ze + th * rho - k1 * nu;
+                        const double inu = 1.0 / (double)nu, rd = (double)rr;
+                        S[4] += inu; S[5] += rd * inu; S[6] += rd * rd * inu; S[7] += (double)nu;
+                    }
+                } else {
+                    // CrossQr pass B: RT log-likelihood with nu_t, then nu_{t+1} (src/Draw.pl.jl:303-320) and rho statistics (:484-485)
+                    const real c = cv[u];
+                    const real nu = nv[u];
+                    if (A.mode == 1) {
+                        const real var_ = k2 * nu;                               // times sig2t_j
+                        const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
+                        llc += (double)(real(-0.5) * ((real)LOG_2PI + lsig + r_log(var_) + r_div(er * er * isig, var_)));
+                        if (post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
+                    }
+                    const real den = r_div(r_sqrt(k2), r_sqrt(isig));            // sqrt(sig2t k2)
+                    const real parA = r_div(r_abs(c - lamc + ze + th * rho), den);
+                    const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
+                    Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, (uint32_t)j, sweep + 1u);
+                    const real nun = qr_weight<real>(st, parA, parB);
+                    A.nu[e] = nun;
+                    const double inu = 1.0 / (double)nun, thd = (double)th;
+                    S[0] += thd * thd * inu;
+                    S[1] += thd * (double)(lamc - ze - c + k1 * nun) * inu;
+                }
+            }
+        }
+        if (jv) {
+#pragma unroll
+            for (int q = 0; q < NSTAT; ++q) acc[q * J + j] = S[q];
+        }
+        ll += llc;
+    }
+
     if (A.dbg_stop == 4) return;
 
     // ---------------- block epilogue: fixed-order reduction of the wave accumulators into this block's slab row
     ll = bfly_sum(ll, 1, 64);
-    if (lane == 0) gtot[NG - 1] = ll;
+    if (lane == 0) sh_gacc[(size_t)wave * NG + NG - 1] = ll;
     __syncthreads();
     const int NS = NSTAT * J + NG;
     double* out = A.slab + (size_t)blockIdx.x * NS;

@@ -128,14 +128,11 @@ template <typename real> struct Engine : EngineBase {
         default: return phase == 0 ? 8 : 2;
         }
     }
-    int rows_sc = 1;
-    size_t pass_lds_fixed(int phase, int nWaves) const {
+    size_t pass_lds(int phase, int nWaves) const {
         const int ng = stat_sizes(phase) - nstat(phase) * J;
         size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * ((size_t)nstat(phase) * J + (size_t)ng);
-        return d * sizeof(double) + (size_t)NITEMARR * J * sizeof(real);
+        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave) * sizeof(real);
     }
-    size_t pass_lds_wave(int rsc) const { return ((size_t)5 * rsc + 4 + (size_t)rsc * J) * sizeof(real) + (size_t)rsc * J; }
-    size_t pass_lds(int phase, int nWaves) const { return pass_lds_fixed(phase, nWaves) + (size_t)nWaves * pass_lds_wave(rows_sc) + 16; }
 
     int init() override {
         N = cfg.n_subj; J = cfg.n_item; F = cfg.n_feat;
@@ -183,12 +180,6 @@ template <typename real> struct Engine : EngineBase {
         rows_per_block = (N + grid_blocks - 1) / grid_blocks;
         grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
         rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
-        {   // super-chunk size: as many subjects per wave as the LDS staging area (logT fp + Y byte per cell) allows
-            const size_t budget = 150 * 1024, fixed = std::max(pass_lds_fixed(0, nWaves), pass_lds_fixed(1, nWaves)) + 64;
-            rows_sc = rows_per_wave;
-            while (rows_sc > 1 && fixed + (size_t)nWaves * pass_lds_wave(rows_sc) > budget) --rows_sc;
-            if (fixed + (size_t)nWaves * pass_lds_wave(rows_sc) > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads");
-        }
         for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
         if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads");
 
@@ -287,7 +278,7 @@ template <typename real> struct Engine : EngineBase {
         a.ctl = dCtl.as<Ctl>();
         a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
         a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
-        a.N = N; a.rows_per_block = rows_per_block; a.rows_per_wave = rows_per_wave; a.rows_sc = rows_sc; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode;
+        a.N = N; a.rows_per_block = rows_per_block; a.rows_per_wave = rows_per_wave; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode;
         a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
