@@ -108,17 +108,18 @@ template <typename real> __device__ __forceinline__ real normal(Stream& s)
     return r_sqrt(real(-2) * r_log(u1)) * r_cos2pi(u2);
 }
 
-// IG(mu, lambda), Michael-Schucany-Haas with the cancellation-free smaller root
+// IG(mu, lambda), Michael-Schucany-Haas.  With y = N^2 and w = mu y the smaller root mu + mu/(2 lambda)(w - sqrt(w (4 lambda + w)))
+// is evaluated as 4 lambda / (y (1 + sqrt(1 + 4 lambda / w))^2): no cancellation, no overflow, and the correct limits
+// x1 -> lambda / y (Levy) as mu -> inf and x1 -> mu as y -> 0.  The first root is kept with probability mu/(mu + x1) = 1/(1 + x1/mu).
 template <typename real> __device__ __forceinline__ real invgauss(Stream& s, real mu, real lambda)
 {
     const real nrm = normal<real>(s);
-    const real w = mu * nrm * nrm;
-    const real sq = r_sqrt(w) * r_sqrt(real(4) * lambda + w);
-    const real den = sq + w;
-    const real q = den > real(0) ? r_div(real(2) * r_sqrt(lambda * w), den) : real(1);   // w -> 0: x1 -> mu
-    const real x1 = mu * q * q;
+    const real y = nrm * nrm;
+    const real w = mu * y;
+    const real t = real(1) + r_sqrt(real(1) + r_div(real(4) * lambda, w));
+    const real x1 = r_div(real(4) * lambda, y * t * t);
     const real u = uniform<real>(s);
-    return (u >= r_div(mu, mu + x1)) ? r_div(mu * mu, x1) : x1;
+    return (u >= r_rcp(real(1) + x1 * r_rcp(mu))) ? r_div(mu * mu, x1) : x1;
 }
 
 // nu = clamp(1 / IG(clamp(parB/parA, 1e-10, Inf), parB^2), 1e-10, 1e10): src/Draw.pl.jl:310-318, 333-341

@@ -97,19 +97,19 @@ static inline double orc_log_pnorm(double x)
     return log(0.5 * erfc(-x * M_SQRT1_2));
 }
 
-/* ---- Inverse Gaussian IG(mu, lambda), Michael-Schucany-Haas; the smaller root is written as
- * mu * (2 sqrt(lambda w) / (s + w))^2 with w = mu*y, s = sqrt(w (4 lambda + w)), which is
- * algebraically mu + mu/(2 lambda) (w - sqrt(w (4 lambda + w))) but free of cancellation. */
+/* ---- Inverse Gaussian IG(mu, lambda), Michael-Schucany-Haas.  With y = N^2 and w = mu y the smaller root
+ * mu + mu/(2 lambda) (w - sqrt(w (4 lambda + w))) is written 4 lambda / (y (1 + sqrt(1 + 4 lambda / w))^2):
+ * algebraically identical, free of cancellation and overflow, with the limits lambda/y (mu -> inf) and mu (y -> 0).
+ * The first root is kept with probability mu/(mu + x1) = 1/(1 + x1/mu). */
 static inline double orc_invgauss(orc_stream* s, double mu, double lambda)
 {
     double n = orc_normal(s);
-    double w = mu * n * n;
-    double sq = sqrt(w) * sqrt(4.0 * lambda + w);
-    double den = sq + w;
-    double q = den > 0.0 ? 2.0 * sqrt(lambda * w) / den : 1.0; /* w -> 0: x1 -> mu */
-    double x1 = mu * q * q;
+    double y = n * n;
+    double w = mu * y;
+    double t = 1.0 + sqrt(1.0 + 4.0 * lambda / w);
+    double x1 = 4.0 * lambda / (y * t * t);
     double u = orc_unif(s);
-    return (u >= mu / (mu + x1)) ? mu * mu / x1 : x1;
+    return (u >= 1.0 / (1.0 + x1 / mu)) ? mu * mu / x1 : x1;
 }
 
 /* ---- standard normal quantile: Giles' (2010) single-precision erfinv polynomial as a starting point,

@@ -77,3 +77,18 @@ def test_item_level_samplers():
     sh = np.exp(g.uniform(0, 13, 20000))        # shapes 1 .. 4e5 (N/2 and 3N/2 at the benchmark sizes)
     d, o = _dev(6, sh.size, sh), pu.orc_sample(6, sh.size, sh)
     assert np.max(np.abs(d - o) / o) < 1e-10
+
+
+def test_qr_weight_survives_degenerate_residuals():
+    """parA == 0 (an exactly zero residual: measure-zero in fp64, reachable in fp32) gives mu = inf; the IG root must stay
+    finite (Levy limit) instead of NaN -- the reference's expression src/Draw.pl.jl:310-312 would propagate a NaN here."""
+    n = 4096
+    pa = np.zeros(n)
+    pa[::2] = 1e-30
+    pb = np.full(n, 1.7)
+    for prec in (0, 1):
+        d = _dev(8, n, pa, pb, precision=prec)
+        assert np.all(np.isfinite(d)) and np.all((d >= 1e-10) & (d <= 1e10))
+    o = pu.orc_sample(8, n, pa, pb)
+    assert np.all(np.isfinite(o))
+    assert np.max(np.abs(_dev(8, n, pa, pb) - o) / o) < 1e-9
