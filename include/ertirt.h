@@ -55,7 +55,7 @@ typedef struct {
     int32_t lanes_per_row;  /* 0 = auto; power of two in [1,64]: lanes that share one subject */
     int32_t block_threads;  /* 0 = auto */
     int32_t grid_blocks;    /* 0 = auto */
-    int32_t profile;        /* 1 = bracket every row-pass launch with HIP events (erm_get_timing) */
+    int32_t profile;        /* 1 = bracket every 8th sweep's row-pass launch with HIP events (erm_get_timing) */
     int32_t reserved;
 } erm_config;
 
