@@ -27,6 +27,16 @@
 
 enum { ORC_MLIRT = 0, ORC_RTIRT = 1, ORC_CROSSQR = 2, ORC_LATENTQR = 3 };
 
+/* OpenMP is used only for the multi-threaded CPU baseline of bench.py: every parallel loop runs over independent subjects,
+ * items or cells whose draws are counter-addressed and whose sums stay inside one iteration, so results are bit-identical
+ * for any thread count (the log-likelihood's reduction is the one exception: its association changes with the team size).
+ * orc_threads defaults to 1, the reference's own execution model. */
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_OMP_FOR ORC_PRAGMA(omp parallel for schedule(static) num_threads(orc_threads))
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return orc_threads; }
+
 typedef struct {
     int32_t model;
     int32_t nItem;
@@ -143,6 +153,7 @@ static void logT_mean_std(const orc_config* c, const orc_data* d, double* mu, do
 static void draw_omega(const orc_config* c, orc_state* s, uint32_t sweep)
 {
     for (int j = 0; j < c->nItem; ++j)
+        ORC_OMP_FOR
         for (int64_t i = 0; i < c->nSubj; ++i) {
             double eta = s->a[j] * (s->theta[i] - s->b[j]);
             orc_stream st = orc_stream_make(c->seed, c->chain, ORC_SITE_OMEGA, (uint32_t)i, (uint32_t)j, sweep);
@@ -157,6 +168,7 @@ static void moments_theta(const orc_config* c, const orc_data* d, const orc_stat
 {
     double s0 = (c->model == ORC_MLIRT) ? 1.0 : s->Sigp[0];
     int p = c->nFeat + 1;
+    ORC_OMP_FOR
     for (int64_t i = 0; i < c->nSubj; ++i) {
         double mu0 = 0.0;
         if (prior) for (int u = 0; u < p; ++u) mu0 += xrow(c, d, s, i, u, 0) * s->beta[u]; /* beta[:,1] = first p entries */
@@ -174,6 +186,7 @@ static void draw_theta(const orc_config* c, const orc_data* d, orc_state* s, int
 {
     double* m = (double*)malloc(sizeof(double) * c->nSubj), *v = (double*)malloc(sizeof(double) * c->nSubj);
     moments_theta(c, d, s, prior, m, v);
+    ORC_OMP_FOR
     for (int64_t i = 0; i < c->nSubj; ++i) {
         orc_stream st = orc_stream_make(c->seed, c->chain, ORC_SITE_THETA, (uint32_t)i, 0, sweep);
         s->theta[i] = m[i] + sqrt(v[i]) * orc_normal(&st);
@@ -184,6 +197,7 @@ static void draw_theta(const orc_config* c, const orc_data* d, orc_state* s, int
 /* drawItemDiscrimination, src/Draw.pl.jl:88-93 (mu_a0 = 1, sigma_a0 = 1) */
 static void moments_a(const orc_config* c, const orc_data* d, const orc_state* s, double* parM, double* parV)
 {
+    ORC_OMP_FOR
     for (int j = 0; j < c->nItem; ++j) {
         double sv = 0, sm = 0;
         for (int64_t i = 0; i < c->nSubj; ++i) {
@@ -209,6 +223,7 @@ static void draw_a(const orc_config* c, const orc_data* d, orc_state* s, uint32_
 /* drawItemDifficulty, src/Draw.pl.jl:98-105 (mu_b0 = 0, sigma_b0 = 1, clamp to [-4,4]) */
 static void moments_b(const orc_config* c, const orc_data* d, const orc_state* s, double* parM, double* parV)
 {
+    ORC_OMP_FOR
     for (int j = 0; j < c->nItem; ++j) {
         double sv = 0, sm = 0;
         for (int64_t i = 0; i < c->nSubj; ++i) {
@@ -235,6 +250,7 @@ static void draw_b(const orc_config* c, const orc_data* d, orc_state* s, uint32_
 static void moments_zeta(const orc_config* c, const orc_data* d, const orc_state* s, double* parM, double* parV)
 {
     const double k1 = k1_of(c->qRt), k2 = k2_of(c->qRt);
+    ORC_OMP_FOR
     for (int64_t i = 0; i < c->nSubj; ++i) {
         double mu0 = 0.0, s0 = s->Sigp[3];
         double sv = 0, sm = 0;
@@ -268,6 +284,7 @@ static void draw_zeta(const orc_config* c, const orc_data* d, orc_state* s, uint
 {
     double* m = (double*)malloc(sizeof(double) * c->nSubj), *v = (double*)malloc(sizeof(double) * c->nSubj);
     moments_zeta(c, d, s, m, v);
+    ORC_OMP_FOR
     for (int64_t i = 0; i < c->nSubj; ++i) {
         /* one block per subject and sweep feeds both row draws: words 0,1 -> theta's normal, words 2,3 -> zeta's */
         orc_stream st = orc_stream_make(c->seed, c->chain, ORC_SITE_THETA, (uint32_t)i, 0, sweep);
@@ -282,6 +299,7 @@ static void moments_lambda(const orc_config* c, const orc_data* d, const orc_sta
 {
     double mu, sd; logT_mean_std(c, d, &mu, &sd);
     const double k1 = k1_of(c->qRt), k2 = k2_of(c->qRt);
+    ORC_OMP_FOR
     for (int j = 0; j < c->nItem; ++j) {
         if (c->model == ORC_CROSSQR) {
             double sv = 0, sm = 0;
@@ -315,6 +333,7 @@ static void draw_lambda(const orc_config* c, const orc_data* d, orc_state* s, ui
 static void moments_sig2t(const orc_config* c, const orc_data* d, const orc_state* s, double* shape, double* scale)
 {
     const double k1 = k1_of(c->qRt), k2 = k2_of(c->qRt);
+    ORC_OMP_FOR
     for (int j = 0; j < c->nItem; ++j) {
         if (c->model == ORC_CROSSQR) {
             double sq = 0, sn = 0;
@@ -359,6 +378,7 @@ static void draw_nu(const orc_config* c, const orc_data* d, orc_state* s, uint32
     if (c->model == ORC_CROSSQR) {
         for (int j = 0; j < c->nItem; ++j) {
             double parB = sqrt(2.0 * k2 + k1 * k1) / sqrt(s->sig2t[j] * k2);
+            ORC_OMP_FOR
             for (int64_t i = 0; i < c->nSubj; ++i) {
                 double parA = fabs(d->logT[IDX(i, j, c->nSubj)] - s->lambda[j] + s->zeta[i] + s->theta[i] * s->rho[j]) / sqrt(s->sig2t[j] * k2);
                 orc_stream st = orc_stream_make(c->seed, c->chain, ORC_SITE_NU, (uint32_t)i, (uint32_t)j, sweep);
@@ -368,6 +388,7 @@ static void draw_nu(const orc_config* c, const orc_data* d, orc_state* s, uint32
     } else { /* LatentQr */
         int p = c->nFeat + 2;
         double parB = sqrt(2.0 * k2 + k1 * k1) / sqrt(s->Sigp[3] * k2);
+        ORC_OMP_FOR
         for (int64_t i = 0; i < c->nSubj; ++i) {
             double xb = 0;
             for (int u = 0; u < p; ++u) xb += xrow(c, d, s, i, u, 1) * s->beta[u];
@@ -519,6 +540,7 @@ static void draw_sigp_latentqr(const orc_config* c, const orc_data* d, orc_state
 static void moments_rho(const orc_config* c, const orc_data* d, const orc_state* s, double* parM, double* parV)
 {
     const double k1 = k1_of(c->qRt), k2 = k2_of(c->qRt);
+    ORC_OMP_FOR
     for (int j = 0; j < c->nItem; ++j) {
         double sv = 0, sm = 0;
         for (int64_t i = 0; i < c->nSubj; ++i) {
@@ -550,6 +572,7 @@ double orc_loglik(const orc_config* c, const orc_data* d, const orc_state* s)
 {
     const double k1 = k1_of(c->qRt), k2 = k2_of(c->qRt);
     double lb = 0, lt = 0, ls = 0;
+    ORC_PRAGMA(omp parallel for reduction(+:lb,lt) schedule(static) num_threads(orc_threads))
     for (int j = 0; j < c->nItem; ++j)
         for (int64_t i = 0; i < c->nSubj; ++i) {
             double eta = s->a[j] * (s->theta[i] - s->b[j]);

@@ -52,6 +52,8 @@ def oracle():
         lib.orc_moments.restype = None
         lib.orc_step.argtypes = [C.POINTER(orc_config), C.POINTER(orc_data), C.POINTER(orc_state), C.c_int, C.c_uint32]
         lib.orc_step.restype = None
+        lib.orc_set_threads.argtypes = [C.c_int]
+        lib.orc_set_threads.restype = None
         _orc = lib
     return _orc
 

@@ -89,3 +89,20 @@ def test_crossqr_chain_is_chaotic():
     free-running over 3 sweeps and teacher-forced afterwards (tests/test_gpu_parity.py)."""
     e = _perturbed_pair("crossqr", 12)
     assert e[0] < 1e-8 and max(e) > 1e-6
+
+
+def test_openmp_oracle_is_bit_identical_to_the_single_thread_run():
+    # the multi-threaded CPU baseline of bench.py must be the same computation: parallel loops only over independent
+    # subjects / items / cells with counter-addressed draws (the log-likelihood reduction is the documented exception)
+    Y, logT, X, init, _ = pu.make_problem("rtirt", 300, 7, 2, seed=5)
+    lib = pu.oracle()
+    try:
+        lib.orc_set_threads(1)
+        a = pu.OracleProblem("rtirt", Y, logT, X, init).run(4)
+        lib.orc_set_threads(4)
+        b = pu.OracleProblem("rtirt", Y, logT, X, init).run(4)
+    finally:
+        lib.orc_set_threads(1)
+    for k in ("ra", "rt", "qr"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.allclose(a["ll"], b["ll"], rtol=1e-12)
