@@ -3,7 +3,8 @@
 Export list mirrors the part of /root/reference/src/ExtendedRtIrtModeling.jl:33-77 that belongs to the hot path.
 """
 from .base import InputData, InputData4R, InputPara, OutputDic, SimConditions, setCond
-from .gibbs import (GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCrossQr, GibbsRtIrtLatentQr, GibbsRtIrtQuantile, coef, getDic,
+from .gibbs import (GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCross, GibbsRtIrtCrossQr, GibbsRtIrtLatent, GibbsRtIrtLatentQr, GibbsRtIrtNull,
+                    GibbsRtIrtQuantile, coef, getDic,
                     getLogLikelihood, precis, sample, sample_b)
 from .simtools import (getBias, getRmse, setDataMlIrt, setDataRtIrt, setDataRtIrtCross, setDataRtIrtLatent,
                        setTrueParaMlIrt, setTrueParaRtIrt, setTrueParaRtIrtCross, setTrueParaRtIrtLatent)
@@ -14,5 +15,5 @@ __all__ = [
     "setDataMlIrt", "setDataRtIrt", "setDataRtIrtCross", "setDataRtIrtLatent",
     "setTrueParaMlIrt", "setTrueParaRtIrt", "setTrueParaRtIrtCross", "setTrueParaRtIrtLatent",
     "getBias", "getRmse", "getDic", "getLogLikelihood", "sample_b", "sample",
-    "GibbsMlIrt", "GibbsRtIrt", "GibbsRtIrtCrossQr", "GibbsRtIrtLatentQr", "GibbsRtIrtQuantile", "coef", "precis",
+    "GibbsMlIrt", "GibbsRtIrt", "GibbsRtIrtCrossQr", "GibbsRtIrtLatentQr", "GibbsRtIrtQuantile", "GibbsRtIrtNull", "GibbsRtIrtCross", "GibbsRtIrtLatent", "coef", "precis",
 ]

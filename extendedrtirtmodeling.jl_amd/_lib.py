@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libertirt.so")
 
 MODEL_MLIRT, MODEL_RTIRT, MODEL_CROSSQR, MODEL_LATENTQR = 0, 1, 2, 3
+MODEL_NULL, MODEL_CROSS, MODEL_LATENT = 4, 5, 6          # the non-quantile variants
 PREC_F32, PREC_F64 = 0, 1
 TRACE_SUMMARY, TRACE_FULL = 0, 1
 TRACE_RA, TRACE_RT, TRACE_QR, TRACE_LOGLIKE = 0, 1, 2, 3
@@ -162,7 +163,8 @@ class Engine:
     def _state_buffers(self, which=None):
         c = self.cfg
         N, J, F = c.n_subj, c.n_item, c.n_feat
-        nb = {MODEL_MLIRT: F + 1, MODEL_RTIRT: 2 * (F + 1), MODEL_LATENTQR: F + 2, MODEL_CROSSQR: 0}[c.model]
+        nb = {MODEL_MLIRT: F + 1, MODEL_RTIRT: 2 * (F + 1), MODEL_LATENTQR: F + 2, MODEL_CROSSQR: 0,
+              MODEL_NULL: 2 * (F + 1), MODEL_CROSS: 0, MODEL_LATENT: F + 2}[c.model]
         nnu = {MODEL_LATENTQR: N, MODEL_CROSSQR: N * J}.get(c.model, 0)
         sizes = dict(theta=N, a=J, b=J, zeta=N, lambda_=J, sig2t=J, beta=nb, sigp=4, rho=J, nu=nnu)
         return {k: (np.zeros(n, dtype=np.float64) if n and (which is None or k in which) else None) for k, n in sizes.items()}

@@ -18,7 +18,14 @@
 
 namespace erm {
 
-enum Model : int { MLIRT = 0, RTIRT = 1, CROSSQR = 2, LATENTQR = 3 };
+enum Model : int { MLIRT = 0, RTIRT = 1, CROSSQR = 2, LATENTQR = 3, NULLM = 4, CROSS = 5, LATENT = 6 };
+// Model families.  The non-quantile variants (GibbsRtIrtNull / Cross / Latent, src/GibbsRtIrt.pl.jl:367-426,
+// src/GibbsRtIrtCross.pl.jl:176-235, src/GibbsRtIrtLatent.pl.jl:168-233) run their quantile sibling's kernels with nu == 1, k1 = 0,
+// k2 = 1 (the host passes those; x*1, x/1 and x+0 are exact) and without any nu traffic; the draws that differ are spelled out.
+__host__ __device__ constexpr bool fam_rt(int M) { return M == RTIRT || M == NULLM; }       // bivariate (theta, zeta) structure, one pass
+__host__ __device__ constexpr bool fam_lq(int M) { return M == LATENTQR || M == LATENT; }   // zeta regressed on [1 X theta], one pass
+__host__ __device__ constexpr bool fam_cq(int M) { return M == CROSSQR || M == CROSS; }     // cross-relation rho, two passes
+__host__ __device__ constexpr bool has_nu(int M) { return M == CROSSQR || M == LATENTQR; }
 
 constexpr int PMAX = 16;            // max columns of the latent-regression design ([1 X theta])
 constexpr int NITEMARR = 8;         // per-item arrays staged in LDS
@@ -49,12 +56,14 @@ __host__ __device__ inline int cst_off_xinv(int J) { return 3 * J + 2 + PMAX * P
 __host__ __device__ inline int cst_size(int J) { return 3 * J + 2 + 2 * PMAX * PMAX; }
 
 // statistics layout of one slab row: NSTAT item statistics x J, then NG globals
-template <int MODEL, int PHASE> struct Stats;
-template <> struct Stats<MLIRT, 0>    { static constexpr int NSTAT = 4; __host__ __device__ static int ng(int p) { return p + 1; } };        // S0 S1 S2 K1 | x'theta, LL
-template <> struct Stats<RTIRT, 0>    { static constexpr int NSTAT = 5; __host__ __device__ static int ng(int p) { return 2 * p + 4; } };    // + G | x'theta, x'zeta, tt, tz, zz, LL
-template <> struct Stats<LATENTQR, 0> { static constexpr int NSTAT = 5; __host__ __device__ static int ng(int p) { return 2 * p + 8; } };    // | x'theta, tt, x'u, tu, uu, snu, snu2, sz, zz, LL
-template <> struct Stats<CROSSQR, 0>  { static constexpr int NSTAT = 8; __host__ __device__ static int ng(int) { return 1; } };              // S0 S1 S2 K1 W0 W1 W2 V | LL_A
-template <> struct Stats<CROSSQR, 1>  { static constexpr int NSTAT = 2; __host__ __device__ static int ng(int) { return 2; } };              // R0 R1 | zz, LL_B
+//   MlIrt        : S0 S1 S2 K1             | x'theta, LL
+//   RtIrt family : S0 S1 S2 K1 G           | x'theta, x'zeta, tt, tz, zz, LL
+//   Latent family: S0 S1 S2 K1 G           | x'theta, tt, x'u, tu, uu, snu, snu2, sz, zz, LL      (u = zeta - k1 nu)
+//   Cross family : S0 S1 S2 K1 W0 W1 W2 V  | LL_A        (pass A)       R0 R1 | zz, LL_B   (pass B)
+template <int MODEL, int PHASE> struct Stats {
+    static constexpr int NSTAT = (MODEL == MLIRT) ? 4 : (fam_cq(MODEL) ? (PHASE == 0 ? 8 : 2) : 5);
+    __host__ __device__ static int ng(int p) { return (MODEL == MLIRT) ? p + 1 : fam_rt(MODEL) ? 2 * p + 4 : fam_lq(MODEL) ? 2 * p + 8 : (PHASE == 0 ? 1 : 2); }
+};
 
 template <typename real> struct PassArgs {
     const uint8_t* Y; const real* C; real* omega; real* nu; const real* X;
@@ -194,7 +203,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     ok4[u] = rowok && (k0 + u) < IPL && j < J;
                     jv4[u] = ok4[u] ? j : 0;
                     const size_t e = base + jv4[u];
-                    wv[u] = (PHASE == 0) ? A.omega[e] : A.nu[e];
+                    wv[u] = (PHASE == 0) ? A.omega[e] : (has_nu(MODEL) ? A.nu[e] : real(1));
                     yv[u] = (PHASE == 0) ? (real)gY[e] : real(0);
                     cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
                 }
@@ -206,7 +215,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                         const real kap = yv[u] - real(0.5);
                         s0 += m * (sh_a2[j] * wv[u]);
                         s1 += m * (sh_a[j] * kap + sh_a2b[j] * wv[u]);
-                        if (MODEL == RTIRT || MODEL == LATENTQR) s2 += m * ((sh_lamc[j] - cv[u]) * sh_isig[j]);
+                        if (fam_rt(MODEL) || fam_lq(MODEL)) s2 += m * ((sh_lamc[j] - cv[u]) * sh_isig[j]);
                     } else {   // CrossQr pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202)
                         const real nu = ok4[u] ? wv[u] : real(1);
                         const real iden = r_div(sh_isig[j], k2 * nu);
@@ -236,7 +245,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         real mu0a = 0, mu0b = 0;
         real xr[8];                                         // first 8 covariates of the subject, loaded once (all loads up front)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xr[u] = (PHASE == 0 && MODEL != CROSSQR && u < F) ? gX[(size_t)i * F + u] : real(0);
+        for (int u = 0; u < 8; ++u) xr[u] = (PHASE == 0 && !fam_cq(MODEL) && u < F) ? gX[(size_t)i * F + u] : real(0);
         auto xcol = [&](int u) -> real {                    // column u of [1 X]
             if (u == 0) return real(1);
             real v = real(0);
@@ -247,7 +256,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             }
             return gX[(size_t)i * F + (u - 1)];
         };
-        if (PHASE == 0 && MODEL != CROSSQR) {
+        if (PHASE == 0 && !fam_cq(MODEL) && MODEL != NULLM) {
             for (int u = 0; u < p; ++u) {
                 const real xu = xcol(u);
                 mu0a += xu * (real)beta[u];
@@ -267,10 +276,11 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 const real parM = parV * (r_div(mu0, sig11) + sB);
                 th = parM + r_sqrt(parV) * row_normal<real>(rw0, rw1);
             }
-            if (MODEL == RTIRT || MODEL == LATENTQR) {
-                // zeta: src/Draw.pl.jl:132-141 / :161-174
+            if (fam_rt(MODEL) || fam_lq(MODEL)) {
+                // zeta: src/Draw.pl.jl:132-141 / :161-174 (LatentQr) / :147-156 (Latent) / :119-127 (Null: prior N(0,1), Sigp unused)
                 real mu0 = mu0b, s0 = sig22;
-                if (MODEL == LATENTQR) {
+                if (MODEL == NULLM) { mu0 = real(0); s0 = real(1); }
+                if (fam_lq(MODEL)) {
                     xb5 = mu0a + th * (real)beta[p];
                     mu0 = xb5 + k1 * nu_row;
                     s0 = sig22 * (k2 * nu_row);
@@ -279,8 +289,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 const real parM = parV * (r_div(mu0, s0) + sC);
                 ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
             }
-            if (MODEL == CROSSQR && PHASE == 1) {
-                // zeta: src/Draw.pl.jl:192-206 (zero prior mean, prior variance Sigp[2,2]); sA = sum of weights here
+            if (fam_cq(MODEL) && PHASE == 1) {
+                // zeta: src/Draw.pl.jl:192-206 (CrossQr) / :179-187 (Cross) (zero prior mean, prior variance Sigp[2,2]); sA = sum of weights here
                 const real parV = r_rcp(r_rcp(sig22) + sA);
                 const real parM = parV * sC;
                 ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     if (A.tr_theta) A.tr_theta[(size_t)trow * A.N + i] = th;
                     if (post_burn) A.sum_theta[i] += (double)th;
                 }
-                if ((MODEL == RTIRT || MODEL == LATENTQR) || (MODEL == CROSSQR && PHASE == 1)) {
+                if (fam_rt(MODEL) || fam_lq(MODEL) || (fam_cq(MODEL) && PHASE == 1)) {
                     A.zeta[i] = ze;
                     if (A.tr_zeta) A.tr_zeta[(size_t)trow * A.N + i] = ze;
                     if (post_burn) A.sum_zeta[i] += (double)ze;
@@ -300,15 +310,17 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 if (MODEL == MLIRT) {
                     const real e = th - mu0a;
                     ll += -0.5 * LOG_2PI - 0.5 * (double)(e * e);
-                } else if (MODEL == RTIRT || (MODEL == CROSSQR && PHASE == 1)) {
+                } else if (fam_rt(MODEL) || (fam_cq(MODEL) && PHASE == 1)) {
                     const double e0 = (double)(th - mu0a), e1 = (double)(ze - mu0b);
                     ll += sp_c0 - 0.5 * (sp_q00 * e0 * e0 + sp_q01 * e0 * e1 + sp_q11 * e1 * e1);
-                } else if (MODEL == LATENTQR) {
+                } else if (fam_lq(MODEL)) {
                     const double var = (double)sig22 * ((double)k2 * (double)nu_row);
                     const double e = (double)(ze - (xb5 + k1 * nu_row));
                     ll += -0.5 * LOG_2PI - 0.5 * log(var) - 0.5 * e * e / var;
-                    if (A.tr_nu) A.tr_nu[(size_t)trow * A.N + i] = nu_row;
-                    if (post_burn) A.sum_nu[i] += (double)nu_row;
+                    if (MODEL == LATENTQR) {
+                        if (A.tr_nu) A.tr_nu[(size_t)trow * A.N + i] = nu_row;
+                        if (post_burn) A.sum_nu[i] += (double)nu_row;
+                    }
                 }
             }
         } else if (MODEL == LATENTQR) {
@@ -342,13 +354,13 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             for (int g = 0; g < NG - 1; ++g) {
                 int ca = 0, cb2 = 0;
                 if (MODEL == MLIRT) { ca = g; cb2 = cT; }
-                else if (MODEL == RTIRT) {
+                else if (fam_rt(MODEL)) {
                     if (g < p) { ca = g; cb2 = cT; }
                     else if (g < 2 * p) { ca = g - p; cb2 = cZ; }
                     else if (g == 2 * p) { ca = cT; cb2 = cT; }
                     else if (g == 2 * p + 1) { ca = cT; cb2 = cZ; }
                     else { ca = cZ; cb2 = cZ; }
-                } else if (MODEL == LATENTQR) {
+                } else if (fam_lq(MODEL)) {
                     if (g < p) { ca = g; cb2 = cT; }
                     else if (g == p) { ca = cT; cb2 = cT; }
                     else if (g < 2 * p + 1) { ca = g - p - 1; cb2 = cU; }
@@ -461,17 +473,17 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     const real c = cv[u];
                     const double wd = (double)w, thd = (double)th;
                     S[0] += wd; S[1] += wd * thd; S[2] += wd * thd * thd; S[3] += y ? 0.5 * thd : -0.5 * thd;
-                    if constexpr (MODEL == RTIRT || MODEL == LATENTQR) S[4] += (double)c * (double)ze;
+                    if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) S[4] += (double)c * (double)ze;
                     if (A.mode == 1) {
                         const real eta = a * (th - b);
                         real t = (y ? eta : real(0)) - log1pexp_r(eta);
-                        if (MODEL == RTIRT || MODEL == LATENTQR) {
+                        if (fam_rt(MODEL) || fam_lq(MODEL)) {
                             const real er = c + ze - lamc;
                             t += real(-0.5) * ((real)LOG_2PI + lsig + er * er * isig);
                         }
                         llc += (double)t;
                     }
-                    if constexpr (MODEL == CROSSQR) {
+                    if constexpr (fam_cq(MODEL)) {
                         // statistics for lambda_t, sig2t_t (src/Draw.pl.jl:246-247, 285) with nu_t, zeta_{t-1}, theta_t, rho_t
                         const real nu = nv[u];
                         const real rr = c + ze + th * rho - k1 * nu;
@@ -486,14 +498,17 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                         const real var_ = k2 * nu;                               // times sig2t_j
                         const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
                         llc += (double)(real(-0.5) * ((real)LOG_2PI + lsig + r_log(var_) + r_div(er * er * isig, var_)));
-                        if (post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
+                        if (has_nu(MODEL) && post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
                     }
                     const real den = r_div(r_sqrt(k2), r_sqrt(isig));            // sqrt(sig2t k2)
                     const real parA = r_div(r_abs(c - lamc + ze + th * rho), den);
                     const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
-                    Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, (uint32_t)j, sweep + 1u);
-                    const real nun = qr_weight<real>(st, parA, parB);
-                    A.nu[e] = nun;
+                    real nun = real(1);
+                    if constexpr (has_nu(MODEL)) {
+                        Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, (uint32_t)j, sweep + 1u);
+                        nun = qr_weight<real>(st, parA, parB);
+                        A.nu[e] = nun;
+                    }
                     const double inu = 1.0 / (double)nun, thd = (double)th;
                     S[0] += thd * thd * inu;
                     S[1] += thd * (double)(lamc - ze - c + k1 * nun) * inu;
@@ -583,6 +598,30 @@ __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
     S[0] = 1.0; S[3] = 1.0;
 }
 
+// lower Cholesky factor of the n x n matrix V (column-major, leading dimension n) into L: one column per step, rows in parallel
+// across the lanes of ONE wave; all lanes of the wave must call it
+__device__ inline void chol_lower_wave(int n, const double* V, double* L, int lane)
+{
+    for (int jj = 0; jj < n; ++jj) {
+        double t = 0.0;
+        if (lane >= jj && lane < n) {
+            t = V[lane + jj * n];
+            for (int k = 0; k < jj; ++k) t -= L[lane + k * n] * L[jj + k * n];
+        }
+        const double d = sqrt(__shfl(t, jj, 64));
+        if (lane >= jj && lane < n) L[lane + jj * n] = (lane == jj) ? d : t / d;
+        wave_sync();
+    }
+}
+// i-th standard normal of stream (BETA, 0, 0, sweep): words 2i, 2i+1, i.e. block i/2 -- the oracle draws them consecutively
+__device__ inline double beta_normal(uint64_t seed, uint32_t chain, uint32_t sweep, int i)
+{
+    uint32_t w0, w1, w2, w3;
+    philox4x32_10(0u, 0u, sweep, ((uint32_t)SITE_BETA << 24) | ((chain & 0xFFu) << 16) | (uint32_t)(i >> 1), (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
+    const double u1 = word_to_unif<double>((i & 1) ? w2 : w0), u2 = word_to_unif<double>((i & 1) ? w3 : w1);
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
 constexpr int TINY_THREADS = 1024;
 constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX + 16;   // LDS scratch doubles for the structural wave
 
@@ -595,8 +634,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     constexpr int NSTAT0 = Stats<MODEL, 0>::NSTAT;
     const int NG0 = Stats<MODEL, 0>::ng(p);
     const int NS0 = NSTAT0 * J + NG0;
-    constexpr int NSTAT1 = (MODEL == CROSSQR) ? Stats<CROSSQR, 1>::NSTAT : 0;
-    const int NG1 = (MODEL == CROSSQR) ? 2 : 0;
+    constexpr int NSTAT1 = fam_cq(MODEL) ? Stats<CROSSQR, 1>::NSTAT : 0;
+    const int NG1 = fam_cq(MODEL) ? 2 : 0;
     const int NS1 = NSTAT1 * J + NG1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -630,9 +669,9 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
         __syncthreads();
     };
     if (tid < T.nb0) T.gcnt0[tid] = 0u;                     // re-arm the group counters for the next pass (kernel boundary orders this)
-    if (MODEL == CROSSQR && tid < T.nb1) T.gcnt1[tid] = 0u;
+    if (fam_cq(MODEL) && tid < T.nb1) T.gcnt1[tid] = 0u;
     reduce(T.slab0, T.nb0, NS0, st0);
-    if (MODEL == CROSSQR && STEP == 0) reduce(T.slab1, T.nb1, NS1, st1);
+    if (fam_cq(MODEL) && STEP == 0) reduce(T.slab1, T.nb1, NS1, st1);
 
     const uint32_t prev_row = T.ctl->row;
     const uint32_t sweep = T.ctl->sweep + ((T.mode == 0 && STEP == 0) ? 1u : 0u);   // the sweep being drawn
@@ -641,7 +680,7 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     // ---- log-likelihood of the sweep the last full pass completed
     if (STEP == 0 && tid == 0 && !T.first && T.tr_ll) {
         double llv = st0[NS0 - 1];
-        if (MODEL == CROSSQR) llv += st1[NS1 - 1];
+        if (fam_cq(MODEL)) llv += st1[NS1 - 1];
         T.tr_ll[prev_row] = llv;
     }
     if (T.mode == 1) return;
@@ -665,7 +704,7 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     double* spd = work + TINY_WORK - 4;
     if (tid == 64 && STEP == 0 && MODEL != MLIRT) {
         Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
-        if (MODEL == RTIRT) {
+        if (fam_rt(MODEL)) {
             const double df = Nd + 3.0;
             spd[0] = sqrt(chisq(ss, df));
             spd[1] = normal<double>(ss);
@@ -686,6 +725,10 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
                 for (int v = 0; v < p; ++v) t += Xinv[lane + v * PMAX] * G0[v];
                 beta[lane] = (lane == 0 && !T.intercept) ? 0.0 : t;
             }
+        } else if (MODEL == NULLM) {
+            // src/GibbsRtIrt.pl.jl:380: Para.beta = zeros(nFeat+1, 2) every sweep
+            if (lane < 2 * p) { bn[lane] = 0.0; beta[(lane / p) * PMAX + (lane % p)] = 0.0; }
+            if (lane < 8) qf[lane] = 0.0;
         } else if (MODEL == RTIRT) {
             // drawSubjCoefficients src/Draw.pl.jl:380-393.  Posterior precision = 11' + kron(inv(Sigp), x'x) (the reference's
             // `1/sigma^2 .+ M` adds 1 to EVERY element), so by Sherman-Morrison
@@ -715,26 +758,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             wave_sync();
             double pm = 0.0;
             if (lane < n) for (int jj = 0; jj < n; ++jj) pm += V[lane + jj * n] * tv[jj];
-            // lower Cholesky factor, one column per step, rows in parallel across lanes
-            for (int jj = 0; jj < n; ++jj) {
-                double t = 0.0;
-                if (lane >= jj && lane < n) {
-                    t = V[lane + jj * n];
-                    for (int k = 0; k < jj; ++k) t -= L[lane + k * n] * L[jj + k * n];
-                }
-                const double d = sqrt(__shfl(t, jj, 64));
-                if (lane >= jj && lane < n) L[lane + jj * n] = (lane == jj) ? d : t / d;
-                wave_sync();
-            }
-            // z_i = i-th normal of stream (BETA, 0, 0, sweep): words 2i, 2i+1, i.e. block i/2 -- drawn by lane i
-            double zi = 0.0;
-            if (lane < n) {
-                uint32_t w0, w1, w2, w3;
-                philox4x32_10(0u, 0u, sweep, ((uint32_t)SITE_BETA << 24) | ((T.chain & 0xFFu) << 16) | (uint32_t)(lane >> 1),
-                              (uint32_t)T.seed, (uint32_t)(T.seed >> 32), w0, w1, w2, w3);
-                const double u1 = word_to_unif<double>((lane & 1) ? w2 : w0), u2 = word_to_unif<double>((lane & 1) ? w3 : w1);
-                zi = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
-            }
+            chol_lower_wave(n, V, L, lane);
+            const double zi = lane < n ? beta_normal(T.seed, T.chain, sweep, lane) : 0.0;     // z_i drawn by lane i
             double t = pm;
             for (int jj = 0; jj < n; ++jj) {
                 const double zj = __shfl(zi, jj, 64);
@@ -753,6 +778,54 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
                 if (lane < 4) { for (int u = 0; u < p; ++u) for (int w = 0; w < p; ++w) v += bn[a_ * p + u] * XtX[u + w * PMAX] * bn[b_ * p + w]; }
                 else { const double* xe = b_ == 0 ? G0 : G0 + p; for (int u = 0; u < p; ++u) v += bn[a_ * p + u] * xe[u]; }
                 qf[lane] = v;
+            }
+        } else if (MODEL == LATENT) {
+            // drawSubjCoefficientsLatent src/Draw.pl.jl:399-416, x = [1 X theta] (q = p + 1 columns):
+            //   parV = inv(11' + x'x / Sigp22)  (`1/sb0^2 .+ M` adds 1 to EVERY element), parM = parV x'zeta / Sigp22,
+            //   beta = parM + chol(Symmetric(parV)).L z
+            const int q = p + 1;
+            double* Mx = work, *L = Mx + q * q, *V = L + q * q, *tv = V + q * q;
+            const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1; const double tz = G0[2 * p + 1];
+            const double iO = 1.0 / Sigp[3];
+            for (int e = lane; e < q * q; e += 64) {
+                const int i = e % q, jj = e / q;
+                const double a_ = (i < p && jj < p) ? XtX[i + jj * PMAX] : ((i == p && jj == p) ? tt : xt[i < jj ? i : jj]);
+                Mx[e] = 1.0 + iO * a_;
+            }
+            if (lane < q) tv[lane] = 0.0 + (lane < p ? xz[lane] : tz) * iO;
+            wave_sync();
+            chol_lower_wave(q, Mx, L, lane);                     // precision = L L'
+            if (lane < q) {                                      // lane k: column k of the inverse (forward, then backward substitution)
+                const int k = lane;
+                for (int i = 0; i < q; ++i) {
+                    double t = (i == k) ? 1.0 : 0.0;
+                    for (int m = 0; m < i; ++m) t -= L[i + m * q] * V[m + k * q];
+                    V[i + k * q] = t / L[i + i * q];
+                }
+                for (int i = q - 1; i >= 0; --i) {
+                    double t = V[i + k * q];
+                    for (int m = i + 1; m < q; ++m) t -= L[m + i * q] * V[m + k * q];
+                    V[i + k * q] = t / L[i + i * q];
+                }
+            }
+            wave_sync();
+            for (int e = lane; e < q * q; e += 64) {             // Symmetric(parV): upper triangle
+                const int i = e % q, jj = e / q;
+                Mx[e] = V[(i < jj ? i : jj) + (i < jj ? jj : i) * q];
+            }
+            wave_sync();
+            double pm = 0.0;
+            if (lane < q) for (int jj = 0; jj < q; ++jj) pm += Mx[lane + jj * q] * tv[jj];
+            chol_lower_wave(q, Mx, L, lane);
+            const double zi = lane < q ? beta_normal(T.seed, T.chain, sweep, lane) : 0.0;
+            double t = pm;
+            for (int jj = 0; jj < q; ++jj) {
+                const double zj = __shfl(zi, jj, 64);
+                if (lane < q && jj <= lane) t += L[lane + jj * q] * zj;
+            }
+            if (lane < q) {
+                if (!T.intercept && lane == 0) t = 0.0;          // src/GibbsRtIrtLatent.pl.jl:184-186
+                bn[lane] = t; beta[lane] = t;
             }
         } else if (MODEL == LATENTQR) {
             // getSubjCoefficientsLatentQr src/Draw.pl.jl:446-458 : beta = (x'x)^-1 x'(zeta - k1 nu), x = [1 X theta];
@@ -785,8 +858,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
         if (STEP == 0) {
             const double S0 = st0[0 * J + j], S1 = st0[1 * J + j], S2 = st0[2 * J + j], K1 = st0[3 * J + j];
             double a = par[j], b = par[J + j];
-            if (MODEL == CROSSQR) {
-                // rho_t: drawSubjCorrCrossQr src/Draw.pl.jl:474-489 (uses sig2t_{t-1})
+            if (fam_cq(MODEL)) {
+                // rho_t: drawSubjCorrCrossQr src/Draw.pl.jl:474-489 / drawSubjCorrCross :463-469 (uses sig2t_{t-1})
                 const double sg = par[3 * J + j];
                 const double R0 = st1[0 * J + j], R1 = st1[1 * J + j];
                 const double parV = 1.0 / (1.0 + R0 / (sg * T.k2));
@@ -812,11 +885,11 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             else { draw_b(); draw_a(); }                  // :301-305
             par[j] = a; par[J + j] = b;
         }
-        if ((MODEL == RTIRT || MODEL == LATENTQR) && STEP == 0) {
+        if ((fam_rt(MODEL) || fam_lq(MODEL)) && STEP == 0) {
             // lambda: drawItemIntensity src/Draw.pl.jl:215-220 ; sig2t: drawItemTimeResidual :257-262
             // sum zeta, sum zeta^2 over subjects (RtIrt: (x'zeta)[0] and zz; LatentQr: tracked explicitly)
-            const double sz = (MODEL == RTIRT) ? G0[p] : G0[2 * p + 5];
-            const double zz = (MODEL == RTIRT) ? G0[2 * p + 2] : G0[2 * p + 6];
+            const double sz = fam_rt(MODEL) ? G0[p] : G0[2 * p + 5];
+            const double zz = fam_rt(MODEL) ? G0[2 * p + 2] : G0[2 * p + 6];
             const double Gj = st0[4 * J + j];
             const double sg_old = par[3 * J + j];
             const double parV = 1.0 / (1.0 / (sdLam * sdLam) + Nd / sg_old);
@@ -830,8 +903,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             par[2 * J + j] = lam; par[3 * J + j] = sg;
             part[j] = 1.0 / sg;
         }
-        if (MODEL == CROSSQR && STEP == 1) {
-            // lambda: drawItemIntensityCrossQr src/Draw.pl.jl:239-251 ; sig2t: drawItemTimeResidualCrossQr :278-288
+        if (fam_cq(MODEL) && STEP == 1) {
+            // lambda: drawItemIntensityCrossQr src/Draw.pl.jl:239-251 / ...Cross :225-231 ; sig2t: drawItemTimeResidualCrossQr :278-288 / ...Cross :267-273
             const double W0 = st0[4 * J + j], W1 = st0[5 * J + j], W2 = st0[6 * J + j], V = st0[7 * J + j];
             const double sg_old = par[3 * J + j];
             const double parV = 1.0 / (1.0 / (sdLam * sdLam) + W0 / (sg_old * T.k2));
@@ -841,11 +914,11 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             const double lc = lam - cm[j];
             const double ssq = (W2 - 2.0 * lc * W1 + lc * lc * W0) / (2.0 * T.k2);
             Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
-            const double sg = invgamma(sv, 1e-3 + Nd * 3.0 / 2.0, 1e-3 + ssq + V);
+            const double sg = (MODEL == CROSSQR) ? invgamma(sv, 1e-3 + Nd * 3.0 / 2.0, 1e-3 + ssq + V) : invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq);
             par[2 * J + j] = lam; par[3 * J + j] = sg;
             part[j] = 1.0 / sg;
         }
-        if (MODEL == MLIRT || (MODEL == CROSSQR && STEP == 0)) part[j] = 1.0 / par[3 * J + j];   // sig2t not drawn in this step
+        if (MODEL == MLIRT || (fam_cq(MODEL) && STEP == 0)) part[j] = 1.0 / par[3 * J + j];   // sig2t not drawn in this step
     }
     __syncthreads();
 
@@ -855,8 +928,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     // =========================================================== Sigma_p_t | beta_t (thread 0; its random numbers were pre-drawn above)
     if (tid == 0 && STEP == 0 && MODEL != MLIRT) {
         double S[4] = { 1.0, 0.0, 0.0, 1.0 };
-        if (MODEL == RTIRT) {
-            // drawSubjCovariance src/Draw.pl.jl:499-515 : InverseWishart(N+3, e'e + I), e'e from sufficient statistics
+        if (fam_rt(MODEL)) {
+            // drawSubjCovariance src/Draw.pl.jl:499-515 (Null: drawSubjCovarianceNull :522-535, the same draw with beta = 0) : InverseWishart(N+3, e'e + I), e'e from sufficient statistics
             // (the quadratic forms beta_a' x'x beta_b and beta_a' x'eta_b were reduced by wave 0 just above: qf[0..7])
             const double tt = G0[2 * p], tz = G0[2 * p + 1], zz = G0[2 * p + 2];
             const double* bAb = qf; const double* bx = qf + 4;
@@ -872,6 +945,17 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
             const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
             S[0] = Wm[3] / det; S[1] = -Wm[1] / det; S[2] = -Wm[2] / det; S[3] = Wm[0] / det;
+        } else if (MODEL == LATENT) {
+            // drawSubjCovarianceLatent src/Draw.pl.jl:563-579 : InverseGamma(da + N/2, db + sum((zeta - x beta)^2)/2), x = [1 X theta]
+            const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1;
+            const double tz = G0[2 * p + 1], zz = G0[2 * p + 2];
+            double sr2 = zz;
+            for (int u = 0; u < p; ++u) sr2 -= 2.0 * bn[u] * xz[u];
+            sr2 -= 2.0 * bn[p] * tz;
+            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
+            for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
+            sr2 += bn[p] * bn[p] * tt;
+            S[3] = (1e-3 + sr2 / 2.0) / spd[0];
         } else if (MODEL == LATENTQR) {
             // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
             const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
@@ -905,8 +989,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
         if (tid < T.nq) {
             double v;
             if (MODEL == MLIRT) v = beta[tid];
-            else if (MODEL == RTIRT) { const int nb = 2 * p; v = tid < nb ? (tid < p ? beta[tid] : beta[PMAX + tid - p]) : Sigp[tid - nb]; }
-            else if (MODEL == CROSSQR) v = tid < J ? par[4 * J + tid] : Sigp[tid - J];
+            else if (fam_rt(MODEL)) { const int nb = 2 * p; v = tid < nb ? (tid < p ? beta[tid] : beta[PMAX + tid - p]) : Sigp[tid - nb]; }
+            else if (fam_cq(MODEL)) v = tid < J ? par[4 * J + tid] : Sigp[tid - J];
             else { const int nb = p + 1; v = tid < nb ? beta[tid] : Sigp[tid - nb]; }
             tr[4 * J + tid] = v;
         }

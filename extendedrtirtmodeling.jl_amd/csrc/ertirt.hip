@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "ertirt.h"
 #include "erm_kernels.hpp"
@@ -66,6 +67,9 @@ struct EngineBase {
             case ERM_MODEL_RTIRT: return 2 * (F + 1) + 4;                                 // :67
             case ERM_MODEL_CROSSQR: return J + 4 + N * J;                                 // src/GibbsRtIrtCross.pl.jl:65
             case ERM_MODEL_LATENTQR: return F + 2 + 4 + N;                                // src/GibbsRtIrtLatent.pl.jl:60
+            case ERM_MODEL_NULL: return 2 * (F + 1) + 4;                                  // OutputPost, src/GibbsRtIrt.pl.jl:67
+            case ERM_MODEL_CROSS: return J + 4;                                           // OutputPostCross, src/GibbsRtIrtCross.pl.jl:46
+            case ERM_MODEL_LATENT: return F + 2 + 4;                                      // OutputPostRtIrtLatent, src/GibbsRtIrtLatent.pl.jl:43
             }
             return 0;
         case ERM_TRACE_LOGLIKE: return 1;
@@ -76,7 +80,8 @@ struct EngineBase {
         switch (cfg.model) {
         case ERM_MODEL_MLIRT: return cfg.n_feat + 1;
         case ERM_MODEL_RTIRT: return 2 * (cfg.n_feat + 1) + 4;
-        case ERM_MODEL_CROSSQR: return cfg.n_item + 4;
+        case ERM_MODEL_CROSSQR: case ERM_MODEL_CROSS: return cfg.n_item + 4;
+        case ERM_MODEL_NULL: return 2 + 4;            // the kernels see no covariates: [beta_theta0, beta_zeta0] = 0, then Sigp
         default: return cfg.n_feat + 2 + 4;
         }
     }
@@ -110,23 +115,31 @@ template <typename real> struct Engine : EngineBase {
     }
 
     bool is_rt() const { return cfg.model != ERM_MODEL_MLIRT; }
+    bool m_cq() const { return fam_cq(cfg.model); }
+    bool m_nu() const { return has_nu(cfg.model); }
     int p() const { return Fk + 1; }
-    int stat_sizes(int phase) const {
-        const int pp = p();
+    // calls f(std::integral_constant<int, MODEL>) for the configured model
+    template <typename Fn> int dispatch(Fn&& f) {
         switch (cfg.model) {
-        case ERM_MODEL_MLIRT: return Stats<MLIRT, 0>::NSTAT * J + Stats<MLIRT, 0>::ng(pp);
-        case ERM_MODEL_RTIRT: return Stats<RTIRT, 0>::NSTAT * J + Stats<RTIRT, 0>::ng(pp);
-        case ERM_MODEL_LATENTQR: return Stats<LATENTQR, 0>::NSTAT * J + Stats<LATENTQR, 0>::ng(pp);
-        default: return phase == 0 ? Stats<CROSSQR, 0>::NSTAT * J + 1 : Stats<CROSSQR, 1>::NSTAT * J + 2;
+        case ERM_MODEL_MLIRT: return f(std::integral_constant<int, MLIRT>{});
+        case ERM_MODEL_RTIRT: return f(std::integral_constant<int, RTIRT>{});
+        case ERM_MODEL_CROSSQR: return f(std::integral_constant<int, CROSSQR>{});
+        case ERM_MODEL_LATENTQR: return f(std::integral_constant<int, LATENTQR>{});
+        case ERM_MODEL_NULL: return f(std::integral_constant<int, NULLM>{});
+        case ERM_MODEL_CROSS: return f(std::integral_constant<int, CROSS>{});
+        case ERM_MODEL_LATENT: return f(std::integral_constant<int, LATENT>{});
         }
+        return fail(ERM_ERR_ARG, "unknown model");
     }
     int nstat(int phase) const {
-        switch (cfg.model) {
-        case ERM_MODEL_MLIRT: return 4;
-        case ERM_MODEL_RTIRT: return 5;
-        case ERM_MODEL_LATENTQR: return 5;
-        default: return phase == 0 ? 8 : 2;
-        }
+        if (cfg.model == ERM_MODEL_MLIRT) return 4;
+        return m_cq() ? (phase == 0 ? 8 : 2) : 5;
+    }
+    int stat_sizes(int phase) const {
+        const int pp = p();
+        int ng = pp + 1;
+        if (fam_rt(cfg.model)) ng = 2 * pp + 4; else if (fam_lq(cfg.model)) ng = 2 * pp + 8; else if (m_cq()) ng = phase == 0 ? 1 : 2;
+        return nstat(phase) * J + ng;
     }
     size_t pass_lds(int phase, int nWaves) const {
         const int ng = stat_sizes(phase) - nstat(phase) * J;
@@ -136,13 +149,13 @@ template <typename real> struct Engine : EngineBase {
 
     int init() override {
         N = cfg.n_subj; J = cfg.n_item; F = cfg.n_feat;
-        Fk = (cfg.model == ERM_MODEL_CROSSQR) ? 0 : F;
+        Fk = (m_cq() || cfg.model == ERM_MODEL_NULL) ? 0 : F;     // the Cross family and Null never touch Data.X
         if (N <= 0 || J <= 0 || F < 0) return fail(ERM_ERR_ARG, "n_subj, n_item must be positive and n_feat non-negative");
         if (N >= (1LL << 32)) return fail(ERM_ERR_ARG, "n_subj must fit 32 bits");
-        if (cfg.model < 0 || cfg.model > 3) return fail(ERM_ERR_ARG, "unknown model");
+        if (cfg.model < 0 || cfg.model > ERM_MODEL_LATENT) return fail(ERM_ERR_ARG, "unknown model");
         if (Fk + 2 > PMAX) return fail(ERM_ERR_ARG, "n_feat too large (max " + std::to_string(PMAX - 2) + ")");
         if (J > 896) return fail(ERM_ERR_ARG, "n_item too large (max 896)");
-        if ((cfg.model == ERM_MODEL_CROSSQR || cfg.model == ERM_MODEL_LATENTQR) && !(cfg.q_rt > 0.0 && cfg.q_rt < 1.0))
+        if (m_nu() && !(cfg.q_rt > 0.0 && cfg.q_rt < 1.0))
             return fail(ERM_ERR_ARG, "qRt must be between 0 and 1");   // @assert at src/Draw.pl.jl:476
         if (cfg.n_iter < 0 || cfg.n_chain < 1 || cfg.n_burnin < 0) return fail(ERM_ERR_ARG, "bad n_iter / n_chain / n_burnin");
         if (cfg.sigp_mode != 0) return fail(ERM_ERR_ARG, "sigp_mode 1 is reserved");
@@ -202,7 +215,7 @@ template <typename real> struct Engine : EngineBase {
         rc |= dSlab0.alloc((size_t)grid_blocks * ns[0] * sizeof(double));
         rc |= dGslab0.alloc((size_t)n_groups * ns[0] * sizeof(double));
         rc |= dGcnt.alloc((size_t)2 * n_groups * sizeof(unsigned int));
-        if (cfg.model == ERM_MODEL_CROSSQR) { rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double)); rc |= dGslab1.alloc((size_t)n_groups * ns[1] * sizeof(double)); }
+        if (m_cq()) { rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double)); rc |= dGslab1.alloc((size_t)n_groups * ns[1] * sizeof(double)); }
         rc |= dCtl.alloc(sizeof(Ctl));
         rc |= dSumTheta.alloc((size_t)N * sizeof(double));
         rc |= dSumZeta.alloc((size_t)N * sizeof(double));
@@ -243,28 +256,21 @@ template <typename real> struct Engine : EngineBase {
     }
     size_t tiny_lds() const {
         const int mx = std::max(ns[0], ns[1]);
-        return (size_t)(ns[0] + (cfg.model == ERM_MODEL_CROSSQR ? ns[1] : 0) + 4 * mx + TINY_WORK + 2 * PMAX * PMAX) * sizeof(double);
+        return (size_t)(ns[0] + (m_cq() ? ns[1] : 0) + 4 * mx + TINY_WORK + 2 * PMAX * PMAX) * sizeof(double);
     }
     int configure_kernels() {
-        switch (cfg.model) {
-        case ERM_MODEL_MLIRT: if (int rc = set_lds_attr<MLIRT, 0>(lds_pass[0])) return rc; break;
-        case ERM_MODEL_RTIRT: if (int rc = set_lds_attr<RTIRT, 0>(lds_pass[0])) return rc; break;
-        case ERM_MODEL_LATENTQR: if (int rc = set_lds_attr<LATENTQR, 0>(lds_pass[0])) return rc; break;
-        default:
-            if (int rc = set_lds_attr<CROSSQR, 0>(lds_pass[0])) return rc;
-            if (int rc = set_lds_attr<CROSSQR, 1>(lds_pass[1])) return rc;
-        }
         const int tl = (int)tiny_lds();
         if (tl > 160 * 1024) return fail(ERM_ERR_ARG, "tiny-step LDS footprint too large");
-        switch (cfg.model) {
-        case ERM_MODEL_MLIRT: HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<MLIRT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl)); break;
-        case ERM_MODEL_RTIRT: HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<RTIRT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl)); break;
-        case ERM_MODEL_LATENTQR: HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<LATENTQR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl)); break;
-        default:
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<CROSSQR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<CROSSQR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
-        }
-        return 0;
+        return dispatch([&](auto m) -> int {
+            constexpr int M = decltype(m)::value;
+            if (int rc = set_lds_attr<M, 0>(lds_pass[0])) return rc;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<M, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
+            if constexpr (fam_cq(M)) {
+                if (int rc = set_lds_attr<M, 1>(lds_pass[1])) return rc;
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<M, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
+            }
+            return 0;
+        });
     }
 
     PassArgs<real> pass_args(int phase, int mode) const {
@@ -282,6 +288,7 @@ template <typename real> struct Engine : EngineBase {
         a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
+        if (!m_nu()) { a.k1 = 0.0; a.k2 = 1.0; }                                   // no quantile weights: nu == 1, k1 = 0, k2 = 1
         { const char* e = getenv("ERM_PASS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
         return a;
     }
@@ -295,6 +302,7 @@ template <typename real> struct Engine : EngineBase {
         t.chain = (uint32_t)cfg.chain_id; t.seed = cfg.seed;
         const double q = cfg.q_rt;
         t.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); t.k2 = 2.0 / (q * (1.0 - q));
+        if (!m_nu()) { t.k1 = 0.0; t.k2 = 1.0; }
         t.nq = nq();
         { const char* e = getenv("ERM_TINY_STOP"); t.dbg_stop = e ? atoi(e) : 0; }
         return t;
@@ -324,7 +332,7 @@ template <typename real> struct Engine : EngineBase {
     template <int MODEL> int enqueue_sweep(bool first, bool timed) {
         if (int rc = launch_tiny<MODEL, 0>(0, first)) return rc;
         if (int rc = launch_pass<MODEL, 0>(1, timed)) return rc;
-        if constexpr (MODEL == CROSSQR) {
+        if constexpr (fam_cq(MODEL)) {
             if (int rc = launch_tiny<MODEL, 1>(0, 0)) return rc;
             if (int rc = launch_pass<MODEL, 1>(1, timed)) return rc;
         }
@@ -345,7 +353,7 @@ template <typename real> struct Engine : EngineBase {
     template <int MODEL> int run_model(int64_t nsweeps) {
         // prologue: omega_{t+1} (and nu_{t+1}) and the statistics of the current state
         if (int rc = launch_pass<MODEL, 0>(0, false)) return rc;
-        if constexpr (MODEL == CROSSQR) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
+        if constexpr (fam_cq(MODEL)) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
         int64_t k = 0;
         if (nsweeps > 0) { if (int rc = enqueue_sweep<MODEL>(true, false)) return rc; k = 1; }
         const bool use_graph = !cfg.profile && getenv("ERM_NO_GRAPH") == nullptr;
@@ -373,14 +381,7 @@ template <typename real> struct Engine : EngineBase {
             for (int k = 0; k < 16; ++k) { HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 2 - 2 * k], stream)); HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 1 - 2 * k], stream)); }
         }
         HIPCHK(hipEventRecord(ev0, stream));
-        int rc = 0;
-        switch (cfg.model) {
-        case ERM_MODEL_MLIRT: rc = run_model<MLIRT>(nsweeps); break;
-        case ERM_MODEL_RTIRT: rc = run_model<RTIRT>(nsweeps); break;
-        case ERM_MODEL_LATENTQR: rc = run_model<LATENTQR>(nsweeps); break;
-        default: rc = run_model<CROSSQR>(nsweeps);
-        }
-        if (rc) return rc;
+        if (int rc = dispatch([&](auto m) -> int { return run_model<decltype(m)::value>(nsweeps); })) return rc;
         HIPCHK(hipEventRecord(ev1, stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
@@ -510,7 +511,8 @@ template <typename real> struct Engine : EngineBase {
         switch (cfg.model) {
         case ERM_MODEL_MLIRT: return F + 1;
         case ERM_MODEL_RTIRT: return 2 * (F + 1);
-        case ERM_MODEL_LATENTQR: return F + 2;
+        case ERM_MODEL_LATENTQR: case ERM_MODEL_LATENT: return F + 2;
+        case ERM_MODEL_NULL: return 2 * (F + 1);          // always zero (src/GibbsRtIrt.pl.jl:380)
         default: return 0;
         }
     }
@@ -544,7 +546,7 @@ template <typename real> struct Engine : EngineBase {
             double* b = &par[par_off_beta(J)];
             const int pp = F + 1;
             if (cfg.model == ERM_MODEL_RTIRT) { for (int u = 0; u < pp; ++u) { b[u] = st->beta[u]; b[PMAX + u] = st->beta[pp + u]; } }
-            else for (int u = 0; u < nbeta(); ++u) b[u] = st->beta[u];
+            else if (cfg.model != ERM_MODEL_NULL) for (int u = 0; u < nbeta(); ++u) b[u] = st->beta[u];
         }
         { double t = 0.0; for (int j = 0; j < J; ++j) t += 1.0 / par[3 * J + j]; par[par_off_derived(J)] = t; }
         HIPCHK(hipMemcpy(dPar.p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -581,6 +583,7 @@ template <typename real> struct Engine : EngineBase {
             const double* b = &par[par_off_beta(J)];
             const int pp = F + 1;
             if (cfg.model == ERM_MODEL_RTIRT) { for (int u = 0; u < pp; ++u) { st->beta[u] = b[u]; st->beta[pp + u] = b[PMAX + u]; } }
+            else if (cfg.model == ERM_MODEL_NULL) for (int u = 0; u < nbeta(); ++u) st->beta[u] = 0.0;
             else for (int u = 0; u < nbeta(); ++u) st->beta[u] = b[u];
         }
         if (st->theta) if (int rc = down_real(dTheta, st->theta, N)) return rc;
@@ -645,6 +648,11 @@ template <typename real> struct Engine : EngineBase {
             for (int64_t r = 0; r < rows_cap; ++r) for (int j = 0; j < J; ++j) { at(r, N + j) = it[r * wi + 2 * J + j]; at(r, N + J + j) = it[r * wi + 3 * J + j]; }
         } else {                                 // qr  :241,319 ; Latent :308
             const int q = nq();
+            if (cfg.model == ERM_MODEL_NULL) {          // [vec(beta) = 0 (2(nFeat+1)); vec(Sigp)]  src/GibbsRtIrt.pl.jl:398
+                const int nb = 2 * ((int)F + 1);
+                for (int64_t r = 0; r < rows_cap; ++r) { for (int k = 0; k < nb; ++k) at(r, k) = 0.0; for (int k = 0; k < 4; ++k) at(r, nb + k) = it[r * wi + 4 * J + 2 + k]; }
+                return 0;
+            }
             for (int64_t r = 0; r < rows_cap; ++r) for (int k = 0; k < q; ++k) at(r, k) = it[r * wi + 4 * J + k];
             if (cfg.model == ERM_MODEL_LATENTQR) if (int rc = subj(dTrNu, q)) return rc;
         }
@@ -684,7 +692,8 @@ template <typename real> struct Engine : EngineBase {
         switch (cfg.model) {
         case ERM_MODEL_MLIRT: if (out->beta) memcpy(out->beta, q, (F + 1) * sizeof(double)); break;
         case ERM_MODEL_RTIRT: if (out->beta) memcpy(out->beta, q, 2 * (F + 1) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + 2 * (F + 1), 4 * sizeof(double)); break;
-        case ERM_MODEL_CROSSQR: if (out->rho) memcpy(out->rho, q, J * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + J, 4 * sizeof(double)); break;
+        case ERM_MODEL_CROSSQR: case ERM_MODEL_CROSS: if (out->rho) memcpy(out->rho, q, J * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + J, 4 * sizeof(double)); break;
+        case ERM_MODEL_NULL: if (out->beta) memset(out->beta, 0, 2 * (F + 1) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + 2, 4 * sizeof(double)); break;
         default: if (out->beta) memcpy(out->beta, q, (F + 2) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + F + 2, 4 * sizeof(double));
         }
         return 0;

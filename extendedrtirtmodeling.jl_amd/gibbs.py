@@ -94,7 +94,7 @@ class _GibbsBase:
             if logT.shape != (C.nSubj, C.nItem):
                 raise ValueError(f"Data.logT must be {C.nSubj}x{C.nItem}, got {logT.shape}")
         X = None
-        if self._model != _lib.MODEL_CROSSQR and C.nFeat > 0:
+        if self._model not in (_lib.MODEL_CROSSQR, _lib.MODEL_CROSS, _lib.MODEL_NULL) and C.nFeat > 0:
             X = np.asarray(D.X, dtype=np.float64)
             if X.shape != (C.nSubj, C.nFeat):
                 raise ValueError(f"Data.X must be {C.nSubj}x{C.nFeat}, got {X.shape}")
@@ -121,7 +121,7 @@ class _GibbsBase:
             mean.Sigp = m["sigp"]
         if m["beta"] is not None:
             mean.beta = m["beta"]
-        if self._model == _lib.MODEL_CROSSQR:
+        if self._model in (_lib.MODEL_CROSSQR, _lib.MODEL_CROSS):
             mean.rho = m["rho"]
         if m["nu"] is not None:
             mean.nu = m["nu"]
@@ -136,9 +136,10 @@ class _GibbsBase:
             P.zeta, P.lam, P.sig2t = s["zeta"], s["lambda_"], s["sig2t"]
             P.Sigp = s["sigp"].reshape(2, 2, order="F")
         if s["beta"] is not None:
-            P.beta = s["beta"].reshape(C.nFeat + 1, 2, order="F") if self._model == _lib.MODEL_RTIRT else s["beta"]
-        if self._model == _lib.MODEL_CROSSQR:
+            P.beta = s["beta"].reshape(C.nFeat + 1, 2, order="F") if self._model in (_lib.MODEL_RTIRT, _lib.MODEL_NULL) else s["beta"]
+        if self._model in (_lib.MODEL_CROSSQR, _lib.MODEL_CROSS):
             P.rho = s["rho"]
+        if self._model == _lib.MODEL_CROSSQR:
             P.nu = s["nu"].reshape(C.nSubj, C.nItem, order="F")
         if self._model == _lib.MODEL_LATENTQR:
             P.nu = s["nu"]
@@ -224,6 +225,44 @@ class GibbsRtIrtLatentQr(_GibbsBase):
         return self
 
 
+class GibbsRtIrtNull(_GibbsBase):
+    """src/GibbsRtIrt.pl.jl:151-183: no latent regression (beta = 0 every sweep, :380), theta ~ N(0, Sigp11), zeta ~ N(0, 1)."""
+    _model = _lib.MODEL_NULL
+    _has_intercept = False
+
+    def setInitialValues(self):
+        C, g = self.Cond, self._rng()
+        self.Para = InputPara(theta=g.standard_normal(C.nSubj), a=np.ones(C.nItem), b=np.zeros(C.nItem),
+                              zeta=g.standard_normal(C.nSubj), lam=np.zeros(C.nItem), sig2t=np.ones(C.nItem), Sigp=np.eye(2))
+        return self
+
+
+class GibbsRtIrtCross(_GibbsBase):
+    """src/GibbsRtIrtCross.pl.jl:77-110: cross-relation rho without quantile weights."""
+    _model = _lib.MODEL_CROSS
+    _has_intercept = False
+
+    def setInitialValues(self):
+        C, g = self.Cond, self._rng()
+        self.Para = InputPara(theta=g.standard_normal(C.nSubj), a=np.ones(C.nItem), b=np.zeros(C.nItem),
+                              zeta=g.standard_normal(C.nSubj), lam=np.zeros(C.nItem), sig2t=np.ones(C.nItem),
+                              rho=g.standard_normal(C.nItem), Sigp=np.eye(2))
+        return self
+
+
+class GibbsRtIrtLatent(_GibbsBase):
+    """src/GibbsRtIrtLatent.pl.jl:70-102 (sample! default cov2one = false, :168): zeta regressed on [1 X theta], beta drawn."""
+    _model = _lib.MODEL_LATENT
+    _cov2one_default = False
+
+    def setInitialValues(self):
+        C, g = self.Cond, self._rng()
+        self.Para = InputPara(theta=g.standard_normal(C.nSubj), a=np.ones(C.nItem), b=np.zeros(C.nItem),
+                              zeta=g.standard_normal(C.nSubj), lam=np.zeros(C.nItem), sig2t=np.ones(C.nItem),
+                              beta=g.standard_normal(C.nFeat + 2), Sigp=np.eye(2))
+        return self
+
+
 # README.md:22,95 names `GibbsRtIrtQuantile`; the export is commented out in the reference (src/ExtendedRtIrtModeling.jl:65) and
 # the only live type with that API (X, beta, Sigp, qRt) is GibbsRtIrtLatentQr.
 GibbsRtIrtQuantile = GibbsRtIrtLatentQr
@@ -241,8 +280,8 @@ def _norm_logpdf(x, mu, sd):
 
 
 def getLogLikelihood(MCMC: _GibbsBase, P: InputPara) -> float:
-    """getLogLikelihoodMlIrt / RtIrt / RtIrtCrossQr / RtIrtLatentQr evaluated at P
-    (src/GibbsRtIrt.pl.jl:195-204,262-272; src/GibbsRtIrtCross.pl.jl:240-258; src/GibbsRtIrtLatent.pl.jl:243-264)."""
+    """getLogLikelihoodMlIrt / RtIrt / RtIrtNull / RtIrtCross(Qr) / RtIrtLatent(Qr) evaluated at P
+    (src/GibbsRtIrt.pl.jl:195-204,262-272,351-362; src/GibbsRtIrtCross.pl.jl:158-170,240-258; src/GibbsRtIrtLatent.pl.jl:151-162,243-264)."""
     C, D = MCMC.Cond, MCMC.Data
     Y = np.asarray(D.Y, dtype=np.float64)
     th, a, b = P.theta, P.a, P.b
@@ -255,14 +294,20 @@ def getLogLikelihood(MCMC: _GibbsBase, P: InputPara) -> float:
     q = C.qRt
     k1, k2 = (1 - 2 * q) / (q * (1 - q)), 2 / (q * (1 - q))
     logT = np.asarray(D.logT, dtype=np.float64)
-    if m == _lib.MODEL_CROSSQR:
+    nu_lat = P.nu
+    if m in (_lib.MODEL_NULL, _lib.MODEL_CROSS, _lib.MODEL_LATENT):
+        k1, k2, nu_lat = 0.0, 1.0, 1.0            # no quantile weights
+    if m == _lib.MODEL_CROSS:
+        mut = P.lam[None, :] - P.zeta[:, None] - th[:, None] * P.rho[None, :]
+        ll += np.sum(_norm_logpdf(logT, mut, np.sqrt(P.sig2t)[None, :]))
+    elif m == _lib.MODEL_CROSSQR:
         e = np.asarray(P.nu).reshape(C.nSubj, C.nItem, order="F")
         mut = P.lam[None, :] - P.zeta[:, None] - th[:, None] * P.rho[None, :] + k1 * e
         ll += np.sum(_norm_logpdf(logT, mut, np.sqrt(P.sig2t[None, :] * (k2 * e))))
     else:
         ll += np.sum(_norm_logpdf(logT, P.lam[None, :] - P.zeta[:, None], np.sqrt(P.sig2t)[None, :]))
     S = np.asarray(P.Sigp, dtype=np.float64).reshape(2, 2, order="F")
-    if m in (_lib.MODEL_RTIRT, _lib.MODEL_CROSSQR):
+    if m in (_lib.MODEL_RTIRT, _lib.MODEL_CROSSQR, _lib.MODEL_NULL, _lib.MODEL_CROSS):
         eta = np.column_stack([th, P.zeta])
         if m == _lib.MODEL_RTIRT:
             x = np.column_stack([np.ones(C.nSubj), D.X])
@@ -272,7 +317,7 @@ def getLogLikelihood(MCMC: _GibbsBase, P: InputPara) -> float:
         ll += np.sum(-np.log(2 * np.pi) - 0.5 * np.log(np.linalg.det(S)) - 0.5 * quad)
     else:
         x = np.column_stack([np.ones(C.nSubj), D.X, th])
-        ll += np.sum(_norm_logpdf(P.zeta, x @ P.beta + k1 * P.nu, np.sqrt(S[1, 1] * k2 * P.nu)))
+        ll += np.sum(_norm_logpdf(P.zeta, x @ P.beta + k1 * nu_lat, np.sqrt(S[1, 1] * k2 * nu_lat)))
     return float(ll)
 
 
@@ -291,11 +336,11 @@ def coef(MCMC: _GibbsBase) -> dict:
     out = {"a": M.a, "b": M.b}
     if MCMC._model != _lib.MODEL_MLIRT:
         out.update({"λ": M.lam, "σ²t": M.sig2t, "Σp": np.asarray(M.Sigp).reshape(2, 2, order="F")})
-    if MCMC._model == _lib.MODEL_RTIRT:
+    if MCMC._model in (_lib.MODEL_RTIRT, _lib.MODEL_NULL):
         out["β"] = np.asarray(M.beta).reshape(C.nFeat + 1, 2, order="F")
     elif M.beta.size:
         out["β"] = M.beta
-    if MCMC._model == _lib.MODEL_CROSSQR:
+    if MCMC._model in (_lib.MODEL_CROSSQR, _lib.MODEL_CROSS):
         out["ρ"] = M.rho
     return out
 

@@ -25,7 +25,11 @@ enum {
     ERM_MODEL_MLIRT = 0,    /* GibbsMlIrt          src/GibbsRtIrt.pl.jl:76-106, sample! :210-257 */
     ERM_MODEL_RTIRT = 1,    /* GibbsRtIrt          src/GibbsRtIrt.pl.jl:114-146, sample! :278-346 */
     ERM_MODEL_CROSSQR = 2,  /* GibbsRtIrtCrossQr   src/GibbsRtIrtCross.pl.jl:115-147, sample! :265-325 */
-    ERM_MODEL_LATENTQR = 3  /* GibbsRtIrtLatentQr  src/GibbsRtIrtLatent.pl.jl:105-137, sample! :271-337 */
+    ERM_MODEL_LATENTQR = 3, /* GibbsRtIrtLatentQr  src/GibbsRtIrtLatent.pl.jl:105-137, sample! :271-337 */
+    /* the non-quantile variants */
+    ERM_MODEL_NULL = 4,     /* GibbsRtIrtNull      src/GibbsRtIrt.pl.jl:151-183, sample! :367-426 (no regression; Data.X ignored) */
+    ERM_MODEL_CROSS = 5,    /* GibbsRtIrtCross     src/GibbsRtIrtCross.pl.jl:77-110, sample! :176-235 */
+    ERM_MODEL_LATENT = 6    /* GibbsRtIrtLatent    src/GibbsRtIrtLatent.pl.jl:70-102, sample! :168-233 */
 };
 enum { ERM_OK = 0, ERM_ERR_ARG = -1, ERM_ERR_HIP = -2, ERM_ERR_STATE = -3, ERM_ERR_NONFINITE = -4, ERM_ERR_NOTRACE = -5, ERM_ERR_NOMEM = -6 };
 enum { ERM_PREC_F32 = 0, ERM_PREC_F64 = 1 };
@@ -61,7 +65,7 @@ typedef struct {
 
 /* Mirrors InputPara (src/Base.pl.jl:100-115).  NULL members are skipped.  Shapes:
  * theta,zeta [nSubj]; a,b,lambda,sig2t,rho [nItem]; sigp [4] = vec(Sigma_p);
- * beta: MlIrt [nFeat+1], RtIrt [(nFeat+1)*2] = vec(beta), LatentQr [nFeat+2];
+ * beta: MlIrt [nFeat+1], RtIrt / Null [(nFeat+1)*2] = vec(beta) (Null: always zero), LatentQr / Latent [nFeat+2];
  * nu: LatentQr [nSubj], CrossQr [nSubj*nItem] column-major. */
 typedef struct {
     double *theta, *a, *b, *zeta, *lambda, *sig2t, *beta, *sigp, *rho, *nu;

@@ -25,7 +25,11 @@
 #include <math.h>
 #include "orc_rng.h"
 
-enum { ORC_MLIRT = 0, ORC_RTIRT = 1, ORC_CROSSQR = 2, ORC_LATENTQR = 3 };
+enum { ORC_MLIRT = 0, ORC_RTIRT = 1, ORC_CROSSQR = 2, ORC_LATENTQR = 3,
+       /* the non-quantile variants */
+       ORC_NULL = 4,    /* GibbsRtIrtNull   src/GibbsRtIrt.pl.jl:151-183, sample! :367-426 */
+       ORC_CROSS = 5,   /* GibbsRtIrtCross  src/GibbsRtIrtCross.pl.jl:77-110, sample! :176-235 */
+       ORC_LATENT = 6   /* GibbsRtIrtLatent src/GibbsRtIrtLatent.pl.jl:70-102, sample! :168-233 */ };
 
 /* OpenMP is used only for the multi-threaded CPU baseline of bench.py: every parallel loop runs over independent subjects,
  * items or cells whose draws are counter-addressed and whose sums stay inside one iteration, so results are bit-identical
@@ -246,7 +250,8 @@ static void draw_b(const orc_config* c, const orc_data* d, orc_state* s, uint32_
     }
 }
 
-/* drawSubjSpeed (src/Draw.pl.jl:132-141), drawSubjSpeedLatentQr (:161-174), drawSubjSpeedCrossQr (:192-206) */
+/* drawSubjSpeed (src/Draw.pl.jl:132-141), drawSubjSpeedLatentQr (:161-174), drawSubjSpeedCrossQr (:192-206),
+ * drawSubjSpeedNull (:119-127: prior N(0, 1), Sigp NOT used), drawSubjSpeedLatent (:147-156), drawSubjSpeedCross (:179-187) */
 static void moments_zeta(const orc_config* c, const orc_data* d, const orc_state* s, double* parM, double* parV)
 {
     const double k1 = k1_of(c->qRt), k2 = k2_of(c->qRt);
@@ -262,8 +267,18 @@ static void moments_zeta(const orc_config* c, const orc_data* d, const orc_state
             for (int u = 0; u < p; ++u) mu0 += xrow(c, d, s, i, u, 1) * s->beta[u];
             mu0 += k1 * s->nu[i];
             s0 = s->Sigp[3] * (k2 * s->nu[i]);
+        } else if (c->model == ORC_LATENT) {
+            int p = c->nFeat + 2;
+            for (int u = 0; u < p; ++u) mu0 += xrow(c, d, s, i, u, 1) * s->beta[u];
+        } else if (c->model == ORC_NULL) {
+            s0 = 1.0;
         }
-        if (c->model == ORC_CROSSQR) {
+        if (c->model == ORC_CROSS) {
+            for (int j = 0; j < c->nItem; ++j) {
+                sv += 1.0 / s->sig2t[j];
+                sm += (s->lambda[j] - d->logT[IDX(i, j, c->nSubj)] - s->theta[i] * s->rho[j]) / s->sig2t[j];
+            }
+        } else if (c->model == ORC_CROSSQR) {
             for (int j = 0; j < c->nItem; ++j) {
                 double nu = s->nu[IDX(i, j, c->nSubj)];
                 double den = s->sig2t[j] * (k2 * nu);
@@ -294,7 +309,7 @@ static void draw_zeta(const orc_config* c, const orc_data* d, orc_state* s, uint
     free(m); free(v);
 }
 
-/* drawItemIntensity (src/Draw.pl.jl:215-220) and drawItemIntensityCrossQr (:239-251) */
+/* drawItemIntensity (src/Draw.pl.jl:215-220), drawItemIntensityCrossQr (:239-251), drawItemIntensityCross (:225-231) */
 static void moments_lambda(const orc_config* c, const orc_data* d, const orc_state* s, double* parM, double* parV)
 {
     double mu, sd; logT_mean_std(c, d, &mu, &sd);
@@ -309,6 +324,11 @@ static void moments_lambda(const orc_config* c, const orc_data* d, const orc_sta
                 sm += (d->logT[IDX(i, j, c->nSubj)] + s->zeta[i] + s->theta[i] * s->rho[j] - k1 * nu) / den;
             }
             parV[j] = 1.0 / (1.0 / (sd * sd) + sv);
+            parM[j] = parV[j] * (mu / (sd * sd) + sm);
+        } else if (c->model == ORC_CROSS) {
+            double sm = 0;
+            for (int64_t i = 0; i < c->nSubj; ++i) sm += (d->logT[IDX(i, j, c->nSubj)] + s->zeta[i] + s->theta[i] * s->rho[j]) / s->sig2t[j];
+            parV[j] = 1.0 / (1.0 / (sd * sd) + (double)c->nSubj / s->sig2t[j]);
             parM[j] = parV[j] * (mu / (sd * sd) + sm);
         } else {
             double sm = 0;
@@ -328,7 +348,8 @@ static void draw_lambda(const orc_config* c, const orc_data* d, orc_state* s, ui
     }
 }
 
-/* drawItemTimeResidual (src/Draw.pl.jl:257-262) and drawItemTimeResidualCrossQr (:278-288); delta_a = delta_b = 1e-3.
+/* drawItemTimeResidual (src/Draw.pl.jl:257-262), drawItemTimeResidualCrossQr (:278-288), drawItemTimeResidualCross (:267-273);
+ * delta_a = delta_b = 1e-3.
  * out: InverseGamma(shape, scale) parameters */
 static void moments_sig2t(const orc_config* c, const orc_data* d, const orc_state* s, double* shape, double* scale)
 {
@@ -345,6 +366,11 @@ static void moments_sig2t(const orc_config* c, const orc_data* d, const orc_stat
             }
             shape[j] = 1e-3 + (double)c->nSubj * 3.0 / 2.0;
             scale[j] = 1e-3 + sq + sn;
+        } else if (c->model == ORC_CROSS) {
+            double sq = 0;
+            for (int64_t i = 0; i < c->nSubj; ++i) { double r = d->logT[IDX(i, j, c->nSubj)] - s->lambda[j] + s->zeta[i] + s->theta[i] * s->rho[j]; sq += r * r; }
+            shape[j] = 1e-3 + (double)c->nSubj / 2.0;
+            scale[j] = 1e-3 + sq / 2.0;
         } else {
             double sq = 0;
             for (int64_t i = 0; i < c->nSubj; ++i) { double r = d->logT[IDX(i, j, c->nSubj)] - s->lambda[j] + s->zeta[i]; sq += r * r; }
@@ -468,14 +494,15 @@ static void cov2one_rescale(double* S) /* src/Draw.pl.jl:507-511 */
     S[0] = 1.0; S[3] = 1.0;
 }
 
-/* drawSubjCovariance, src/Draw.pl.jl:499-515: s ~ InverseWishart(N+3, e'e + I2) (inverse of a Bartlett Wishart) */
+/* drawSubjCovariance, src/Draw.pl.jl:499-515: s ~ InverseWishart(N+3, e'e + I2) (inverse of a Bartlett Wishart);
+ * drawSubjCovarianceNull, :522-535, is the same draw with e = eta (no regression) */
 static void scale_sigp_rtirt(const orc_config* c, const orc_data* d, const orc_state* s, double* Psi)
 {
     int p = c->nFeat + 1;
     double e00 = 0, e01 = 0, e11 = 0;
     for (int64_t i = 0; i < c->nSubj; ++i) {
         double m0 = 0, m1 = 0;
-        for (int u = 0; u < p; ++u) { double x = xrow(c, d, s, i, u, 0); m0 += x * s->beta[u]; m1 += x * s->beta[p + u]; }
+        if (c->model != ORC_NULL) for (int u = 0; u < p; ++u) { double x = xrow(c, d, s, i, u, 0); m0 += x * s->beta[u]; m1 += x * s->beta[p + u]; }
         double e0 = s->theta[i] - m0, e1 = s->zeta[i] - m1;
         e00 += e0 * e0; e01 += e0 * e1; e11 += e1 * e1;
     }
@@ -536,13 +563,66 @@ static void draw_sigp_latentqr(const orc_config* c, const orc_data* d, orc_state
     if (c->cov2one) cov2one_rescale(s->Sigp);
 }
 
-/* drawSubjCorrCrossQr, src/Draw.pl.jl:474-489 (sigma_rho = 1) */
+/* drawSubjCoefficientsLatent, src/Draw.pl.jl:399-416: invO = 1/Sigp[2,2]; parV = inv(1/sb0^2 .+ invO x'x) (the `.+` adds 1 to
+ * EVERY element, as in drawSubjCoefficients); parM = parV (0 .+ x'zeta invO); beta = parM + chol(parV).L randn(nFeat+2); x = [1 X theta] */
+static void moments_beta_latent(const orc_config* c, const orc_data* d, const orc_state* s, double* parM, double* parV)
+{
+    int q = c->nFeat + 2;
+    double A[q * q], P[q * q], t[q];
+    const double iO = 1.0 / s->Sigp[3];
+    xtx(c, d, s, q, 1, A);
+    for (int u = 0; u < q; ++u) { double acc = 0; for (int64_t i = 0; i < c->nSubj; ++i) acc += xrow(c, d, s, i, u, 1) * s->zeta[i]; t[u] = 0.0 + acc * iO; }
+    for (int e = 0; e < q * q; ++e) P[e] = 1.0 + iO * A[e];
+    mat_inverse(q, P, parV);
+    for (int i = 0; i < q; ++i) { double acc = 0; for (int j = 0; j < q; ++j) acc += parV[i + j * q] * t[j]; parM[i] = acc; }
+}
+static void draw_beta_latent(const orc_config* c, const orc_data* d, orc_state* s, uint32_t sweep)
+{
+    int q = c->nFeat + 2;
+    double parM[q], parV[q * q], L[q * q], z[q];
+    moments_beta_latent(c, d, s, parM, parV);
+    for (int i = 0; i < q; ++i) for (int j = 0; j < i; ++j) parV[i + j * q] = parV[j + i * q];   /* Symmetric(parV): upper triangle */
+    chol_lower(q, parV, L);
+    orc_stream st = orc_stream_make(c->seed, c->chain, ORC_SITE_BETA, 0, 0, sweep);
+    for (int i = 0; i < q; ++i) z[i] = orc_normal(&st);
+    for (int i = 0; i < q; ++i) { double acc = parM[i]; for (int j = 0; j <= i; ++j) acc += L[i + j * q] * z[j]; s->beta[i] = acc; }
+    if (!c->intercept) s->beta[0] = 0.0; /* src/GibbsRtIrtLatent.pl.jl:184-186 */
+}
+
+/* drawSubjCovarianceLatent, src/Draw.pl.jl:563-579: s ~ InverseGamma(da + N/2, db + sum((zeta - x beta)^2)/2), Sigp = [1 0; 0 s] */
+static double scale_sigp_latent(const orc_config* c, const orc_data* d, const orc_state* s)
+{
+    int q = c->nFeat + 2;
+    double sq = 0;
+    for (int64_t i = 0; i < c->nSubj; ++i) {
+        double xb = 0;
+        for (int u = 0; u < q; ++u) xb += xrow(c, d, s, i, u, 1) * s->beta[u];
+        sq += (s->zeta[i] - xb) * (s->zeta[i] - xb);
+    }
+    return 1e-3 + sq / 2.0;
+}
+static void draw_sigp_latent(const orc_config* c, const orc_data* d, orc_state* s, uint32_t sweep)
+{
+    double parB = scale_sigp_latent(c, d, s);
+    orc_stream st = orc_stream_make(c->seed, c->chain, ORC_SITE_SIGP, 0, 0, sweep);
+    double v = orc_invgamma(&st, 1e-3 + (double)c->nSubj / 2.0, parB);
+    s->Sigp[0] = 1.0; s->Sigp[1] = 0.0; s->Sigp[2] = 0.0; s->Sigp[3] = v;
+    if (c->cov2one) cov2one_rescale(s->Sigp);
+}
+
+/* drawSubjCorrCrossQr, src/Draw.pl.jl:474-489, and drawSubjCorrCross, :463-469 (sigma_rho = 1) */
 static void moments_rho(const orc_config* c, const orc_data* d, const orc_state* s, double* parM, double* parV)
 {
     const double k1 = k1_of(c->qRt), k2 = k2_of(c->qRt);
     ORC_OMP_FOR
     for (int j = 0; j < c->nItem; ++j) {
         double sv = 0, sm = 0;
+        if (c->model == ORC_CROSS) {
+            for (int64_t i = 0; i < c->nSubj; ++i) {
+                sv += s->theta[i] * s->theta[i] / s->sig2t[j];
+                sm += s->theta[i] * (s->lambda[j] - s->zeta[i] - d->logT[IDX(i, j, c->nSubj)]) / s->sig2t[j];
+            }
+        } else
         for (int64_t i = 0; i < c->nSubj; ++i) {
             double nu = s->nu[IDX(i, j, c->nSubj)], den = s->sig2t[j] * (k2 * nu);
             sv += s->theta[i] * s->theta[i] / den;
@@ -577,8 +657,10 @@ double orc_loglik(const orc_config* c, const orc_data* d, const orc_state* s)
         for (int64_t i = 0; i < c->nSubj; ++i) {
             double eta = s->a[j] * (s->theta[i] - s->b[j]);
             lb += (d->Y[IDX(i, j, c->nSubj)] ? eta : 0.0) - log1pexp(eta);
-            if (c->model == ORC_RTIRT || c->model == ORC_LATENTQR)
+            if (c->model == ORC_RTIRT || c->model == ORC_LATENTQR || c->model == ORC_NULL || c->model == ORC_LATENT)
                 lt += logpdf_normal(d->logT[IDX(i, j, c->nSubj)], s->lambda[j] - s->zeta[i], sqrt(s->sig2t[j]));
+            else if (c->model == ORC_CROSS)   /* src/GibbsRtIrtCross.pl.jl:158-170 */
+                lt += logpdf_normal(d->logT[IDX(i, j, c->nSubj)], s->lambda[j] - s->zeta[i] - s->theta[i] * s->rho[j], sqrt(s->sig2t[j]));
             else if (c->model == ORC_CROSSQR) {
                 double nu = s->nu[IDX(i, j, c->nSubj)];
                 lt += logpdf_normal(d->logT[IDX(i, j, c->nSubj)], s->lambda[j] - s->zeta[i] - s->theta[i] * s->rho[j] + k1 * nu,
@@ -591,7 +673,8 @@ double orc_loglik(const orc_config* c, const orc_data* d, const orc_state* s)
             double mu = 0; for (int u = 0; u < p; ++u) mu += xrow(c, d, s, i, u, 0) * s->beta[u];
             ls += logpdf_normal(s->theta[i], mu, 1.0);
         }
-    } else if (c->model == ORC_RTIRT || c->model == ORC_CROSSQR) {
+    } else if (c->model == ORC_RTIRT || c->model == ORC_CROSSQR || c->model == ORC_NULL || c->model == ORC_CROSS) {
+        /* Null / Cross: zero mean (src/GibbsRtIrt.pl.jl:351-362, src/GibbsRtIrtCross.pl.jl:158-170) */
         int p = c->nFeat + 1;
         double Si[4]; mat_inverse(2, s->Sigp, Si);
         double logdet = log(s->Sigp[0] * s->Sigp[3] - s->Sigp[1] * s->Sigp[2]);
@@ -600,6 +683,12 @@ double orc_loglik(const orc_config* c, const orc_data* d, const orc_state* s)
             if (c->model == ORC_RTIRT) for (int u = 0; u < p; ++u) { double x = xrow(c, d, s, i, u, 0); m0 += x * s->beta[u]; m1 += x * s->beta[p + u]; }
             double e0 = s->theta[i] - m0, e1 = s->zeta[i] - m1;
             ls += -LOG_2PI - 0.5 * logdet - 0.5 * (e0 * (Si[0] * e0 + Si[2] * e1) + e1 * (Si[1] * e0 + Si[3] * e1));
+        }
+    } else if (c->model == ORC_LATENT) { /* src/GibbsRtIrtLatent.pl.jl:151-162 */
+        int p = c->nFeat + 2;
+        for (int64_t i = 0; i < c->nSubj; ++i) {
+            double mu = 0; for (int u = 0; u < p; ++u) mu += xrow(c, d, s, i, u, 1) * s->beta[u];
+            ls += logpdf_normal(s->zeta[i], mu, sqrt(s->Sigp[3]));
         }
     } else { /* LatentQr */
         int p = c->nFeat + 2;
@@ -657,6 +746,39 @@ static void sweep_once(const orc_config* c, const orc_data* d, orc_state* s, uin
         draw_sig2t(c, d, s, t);
         draw_zeta(c, d, s, t);
         break;
+    case ORC_NULL: /* src/GibbsRtIrt.pl.jl:378-404: beta = 0 -> Sigp(Null) -> omega -> b -> a -> theta(Null) -> lambda -> sig2t -> zeta(Null) */
+        memset(s->beta, 0, sizeof(double) * 2 * (c->nFeat + 1));
+        draw_sigp_rtirt(c, d, s, t);
+        draw_omega(c, s, t);
+        draw_b(c, d, s, t);
+        draw_a(c, d, s, t);
+        draw_theta(c, d, s, 0, t);
+        draw_lambda(c, d, s, t);
+        draw_sig2t(c, d, s, t);
+        draw_zeta(c, d, s, t);
+        break;
+    case ORC_CROSS: /* src/GibbsRtIrtCross.pl.jl:187-213: rho -> Sigp -> omega -> b -> a -> theta(Null) -> lambda -> sig2t -> zeta */
+        draw_rho(c, d, s, t);
+        draw_sigp_cross(c, s, t);
+        draw_omega(c, s, t);
+        draw_b(c, d, s, t);
+        draw_a(c, d, s, t);
+        draw_theta(c, d, s, 0, t);
+        draw_lambda(c, d, s, t);
+        draw_sig2t(c, d, s, t);
+        draw_zeta(c, d, s, t);
+        break;
+    case ORC_LATENT: /* src/GibbsRtIrtLatent.pl.jl:179-211: beta(draw) -> Sigp -> omega -> b -> a -> theta(Null) -> lambda -> sig2t -> zeta */
+        draw_beta_latent(c, d, s, t);
+        draw_sigp_latent(c, d, s, t);
+        draw_omega(c, s, t);
+        draw_b(c, d, s, t);
+        draw_a(c, d, s, t);
+        draw_theta(c, d, s, 0, t);
+        draw_lambda(c, d, s, t);
+        draw_sig2t(c, d, s, t);
+        draw_zeta(c, d, s, t);
+        break;
     }
 }
 
@@ -667,6 +789,9 @@ int orc_qr_width(const orc_config* c, int with_nu)
     case ORC_RTIRT: return 2 * (c->nFeat + 1) + 4;                         /* :67 */
     case ORC_CROSSQR: return c->nItem + 4 + (with_nu ? (int)(c->nSubj * c->nItem) : 0); /* src/GibbsRtIrtCross.pl.jl:65 */
     case ORC_LATENTQR: return c->nFeat + 2 + 4 + (with_nu ? (int)c->nSubj : 0);          /* src/GibbsRtIrtLatent.pl.jl:60 */
+    case ORC_NULL: return 2 * (c->nFeat + 1) + 4;                          /* OutputPost, src/GibbsRtIrt.pl.jl:67 */
+    case ORC_CROSS: return c->nItem + 4;                                   /* OutputPostCross, src/GibbsRtIrtCross.pl.jl:36-50 */
+    case ORC_LATENT: return c->nFeat + 2 + 4;                              /* OutputPostRtIrtLatent, src/GibbsRtIrtLatent.pl.jl:33-47 */
     }
     return 0;
 }
@@ -687,9 +812,9 @@ int orc_run(const orc_config* c, const orc_data* d, orc_state* s, int64_t sweep0
         if (tr_qr) {
             double* r = tr_qr + (size_t)k * wq; int o = 0;
             if (c->model == ORC_MLIRT) { memcpy(r, s->beta, sizeof(double) * (c->nFeat + 1)); }
-            else if (c->model == ORC_RTIRT) { int nb = 2 * (c->nFeat + 1); memcpy(r, s->beta, sizeof(double) * nb); memcpy(r + nb, s->Sigp, sizeof(double) * 4); }
-            else if (c->model == ORC_CROSSQR) { memcpy(r, s->rho, sizeof(double) * J); o = J; memcpy(r + o, s->Sigp, sizeof(double) * 4); o += 4; if (qr_with_nu) memcpy(r + o, s->nu, sizeof(double) * N * J); }
-            else { int nb = c->nFeat + 2; memcpy(r, s->beta, sizeof(double) * nb); o = nb; memcpy(r + o, s->Sigp, sizeof(double) * 4); o += 4; if (qr_with_nu) memcpy(r + o, s->nu, sizeof(double) * N); }
+            else if (c->model == ORC_RTIRT || c->model == ORC_NULL) { int nb = 2 * (c->nFeat + 1); memcpy(r, s->beta, sizeof(double) * nb); memcpy(r + nb, s->Sigp, sizeof(double) * 4); }
+            else if (c->model == ORC_CROSSQR || c->model == ORC_CROSS) { memcpy(r, s->rho, sizeof(double) * J); o = J; memcpy(r + o, s->Sigp, sizeof(double) * 4); o += 4; if (qr_with_nu && c->model == ORC_CROSSQR) memcpy(r + o, s->nu, sizeof(double) * N * J); }
+            else { int nb = c->nFeat + 2; memcpy(r, s->beta, sizeof(double) * nb); o = nb; memcpy(r + o, s->Sigp, sizeof(double) * 4); o += 4; if (qr_with_nu && c->model == ORC_LATENTQR) memcpy(r + o, s->nu, sizeof(double) * N); }
         }
         if (tr_ll) tr_ll[k] = orc_loglik(c, d, s);
     }
@@ -737,6 +862,8 @@ void orc_moments(const orc_config* c, const orc_data* d, const orc_state* s, int
     case 8: moments_beta_rtirt(c, d, s, out1, out2); break;
     case 9: scale_sigp_rtirt(c, d, s, out1); break;
     case 10: out1[0] = scale_sigp_latentqr(c, d, s); break;
+    case 11: moments_beta_latent(c, d, s, out1, out2); break;
+    case 12: out1[0] = scale_sigp_latent(c, d, s); break;
     }
 }
 
@@ -760,5 +887,7 @@ void orc_step(const orc_config* c, const orc_data* d, orc_state* s, int step, ui
     case 13: get_beta_latentqr(c, d, s); break;
     case 14: draw_sigp_latentqr(c, d, s, t); break;
     case 15: draw_sigp_cross(c, s, t); break;
+    case 16: draw_beta_latent(c, d, s, t); break;
+    case 17: draw_sigp_latent(c, d, s, t); break;
     }
 }

@@ -11,13 +11,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import parity_util as pu  # noqa: E402
 
-CASES = {"mlirt": (160, 7, 3), "rtirt": (160, 7, 3), "latentqr": (160, 7, 3), "crossqr": (160, 7, 0)}
+CASES = {"mlirt": (160, 7, 3), "rtirt": (160, 7, 3), "latentqr": (160, 7, 3), "crossqr": (160, 7, 0),
+         "null": (160, 7, 3), "cross": (160, 7, 0), "latent": (160, 7, 3)}
 T = 6
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for model, (N, J, F) in CASES.items():
-        Y, logT, X, init, _ = pu.make_problem(model, N, J, max(F, 3) if model != "crossqr" else 3, seed=21)
-        op = pu.OracleProblem(model, Y, logT, X, init, qRt=0.85, cov2one=(model != "latentqr"), seed=1234)
+        if only and model not in only:
+            continue
+        Y, logT, X, init, _ = pu.make_problem(model, N, J, 3, seed=21)
+        op = pu.OracleProblem(model, Y, logT, X, init, qRt=0.85, cov2one=(model not in ("latentqr", "latent")), seed=1234)
         tr = op.run(T, with_nu=(model == "latentqr"))
         out = dict(Y=Y.astype(np.uint8), T=T, qRt=0.85, seed=1234, ra=tr["ra"], rt=tr["rt"], qr=tr["qr"], ll=tr["ll"])
         if logT is not None:

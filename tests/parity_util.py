@@ -13,7 +13,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-MODELS = {"mlirt": 0, "rtirt": 1, "crossqr": 2, "latentqr": 3}
+MODELS = {"mlirt": 0, "rtirt": 1, "crossqr": 2, "latentqr": 3, "null": 4, "cross": 5, "latent": 6}
+BASE = {"null": "rtirt", "cross": "crossqr", "latent": "latentqr"}      # data generator / layout family of each variant
 _DP = C.POINTER(C.c_double)
 
 
@@ -81,7 +82,7 @@ class OracleProblem:
         self.data = orc_data(self.Y.ctypes.data, None if self.logT is None else self.logT.ctypes.data,
                              None if self.X is None else self.X.ctypes.data)
         N, J, F = self.N, self.J, self.F
-        nb = {0: F + 1, 1: 2 * (F + 1), 2: 1, 3: F + 2}[self.model]
+        nb = {0: F + 1, 1: 2 * (F + 1), 2: 1, 3: F + 2, 4: 2 * (F + 1), 5: 1, 6: F + 2}[self.model]
         nnu = {2: N * J, 3: N}.get(self.model, 1)
         self.arr = dict(theta=np.zeros(N), a=np.ones(J), b=np.zeros(J), zeta=np.zeros(N), lambda_=np.zeros(J), sig2t=np.ones(J),
                         beta=np.zeros(nb), Sigp=np.array([1.0, 0, 0, 1.0]), rho=np.zeros(J), nu=np.ones(nnu), omega=np.zeros(N * J))
@@ -129,17 +130,21 @@ def make_problem(model, N, J, F=3, seed=7, qRt=0.85):
         D = pkg.setDataMlIrt(Cond, tp, seed=g)
         init = dict(theta=g.standard_normal(N), beta=g.standard_normal(F + 1))
         return D.Y, None, D.X, init, tp
-    if model == "rtirt":
+    if model in ("rtirt", "null"):
         tp = pkg.setTrueParaRtIrt(Cond, seed=g)
+        if model == "null":
+            tp.beta = np.zeros((F, 2))          # the Null model has no covariate effects: theta, zeta ~ N(0, Sigp)
         D = pkg.setDataRtIrt(Cond, tp, seed=g)
         init = dict(theta=g.standard_normal(N), zeta=g.standard_normal(N), beta=g.standard_normal((F + 1, 2)), sigp=np.eye(2))
+        if model == "null":
+            init["beta"] = np.zeros((F + 1, 2))
         return D.Y, D.logT, D.X, init, tp
-    if model == "crossqr":
+    if model in ("crossqr", "cross"):
         tp = pkg.setTrueParaRtIrtCross(Cond, seed=g)
         D = pkg.setDataRtIrtCross(Cond, tp, seed=g)
         init = dict(theta=g.standard_normal(N), zeta=g.standard_normal(N), rho=g.standard_normal(J), sigp=np.eye(2))
         return D.Y, D.logT, None, init, tp
-    if model == "latentqr":
+    if model in ("latentqr", "latent"):
         tp = pkg.setTrueParaRtIrtLatent(Cond, seed=g)
         D = pkg.setDataRtIrtLatent(Cond, tp, seed=g)
         init = dict(theta=g.standard_normal(N), zeta=g.standard_normal(N), beta=g.standard_normal(F + 2), sigp=np.eye(2))
@@ -154,7 +159,7 @@ def run_device(model, Y, logT, X, init, nsweeps, *, precision="f64", qRt=0.85, s
     N, J = Y.shape
     F = 0 if X is None else X.shape[1]
     if cov2one is None:
-        cov2one = model != "latentqr"
+        cov2one = model not in ("latentqr", "latent")
     nb = nsweeps // 2 if n_burnin is None else n_burnin
     eng = L.Engine(model=MODELS[model], n_item=J, n_subj=N, n_feat=F, n_iter=nsweeps // n_chain, n_chain=n_chain, n_burnin=nb,
                    intercept=int(intercept), one_pl=int(onepl), cov2one=int(cov2one), q_rt=qRt, seed=seed,
@@ -178,7 +183,7 @@ def run_pair(model, N, J, nsweeps, *, F=3, precision="f64", seed=7, qRt=0.85, **
     Y, logT, X, init, tp = make_problem(model, N, J, F, seed=seed, qRt=qRt)
     cov2one = kw.get("cov2one")
     if cov2one is None:
-        cov2one = model != "latentqr"
+        cov2one = model not in ("latentqr", "latent")
     dev = run_device(model, Y, logT, X, init, nsweeps, precision=precision, qRt=qRt, **kw)
     op = OracleProblem(model, Y, logT, X, init, qRt=qRt, intercept=kw.get("intercept", False), onepl=kw.get("onepl", False),
                        cov2one=cov2one, seed=kw.get("seed", 1234))

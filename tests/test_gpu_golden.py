@@ -9,7 +9,7 @@ from test_oracle_sweeps import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("model", ["mlirt", "rtirt", "latentqr", "crossqr"])
+@pytest.mark.parametrize("model", ["mlirt", "rtirt", "latentqr", "crossqr", "null", "cross", "latent"])
 def test_engine_reproduces_golden_traces(model):
     z, Y, logT, X, init = load_golden(model)
     T = int(z["T"]) if model != "crossqr" else 3
@@ -47,3 +47,30 @@ def test_sample_bang_fills_post_like_the_reference():
     M1 = pkg.GibbsRtIrt(Cond, Data=M.Data, precision="f64")
     pkg.sample_b(M1, itemtype="1pl")
     assert np.all(M1.Post.ra[:, N:N + J, :] == 1)
+
+
+@pytest.mark.parametrize("name,model", [("GibbsRtIrtNull", "null"), ("GibbsRtIrtCross", "cross"), ("GibbsRtIrtLatent", "latent")])
+def test_variant_samplers_fill_post_like_the_reference(name, model):
+    """GibbsRtIrtNull / Cross / Latent through the Julia-surface mirror: Post widths of OutputPost / OutputPostCross /
+    OutputPostRtIrtLatent (src/GibbsRtIrt.pl.jl:67, src/GibbsRtIrtCross.pl.jl:46, src/GibbsRtIrtLatent.pl.jl:43), Post.mean fields
+    of each sample! (:407-423, :216-232, :214-230), DIC."""
+    pkg = pu.ge.load_package()
+    z, Y, logT, X, init = load_golden(model)
+    N, J = Y.shape
+    Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=3, nIter=6, nChain=2)
+    D = pkg.InputData(Y=Y, T=np.exp(logT), X=X if X is not None else np.zeros((N, 3)))
+    M = getattr(pkg, name)(Cond, Data=D, precision="f64")
+    pkg.sample_b(M)
+    P = M.Post
+    wq = {"null": 12, "cross": J + 4, "latent": 9}[model]
+    assert P.ra.shape == (6, N + 2 * J, 2) and P.rt.shape == (6, N + 2 * J, 2) and P.qr.shape == (6, wq, 2) and P.logLike.shape == (6, 1, 2)
+    assert np.allclose(P.mean.theta, P.ra[3:, :N, :].mean(axis=(0, 2))) and np.allclose(P.mean.lam, P.rt[3:, N:N + J, :].mean(axis=(0, 2)))
+    if model == "null":
+        assert np.all(P.qr[:, :8, :] == 0) and np.all(P.mean.beta == 0) and np.allclose(P.mean.Sigp, P.qr[3:, 8:, :].mean(axis=(0, 2)))
+    if model == "cross":
+        assert np.allclose(P.mean.rho, P.qr[3:, :J, :].mean(axis=(0, 2))) and np.all(P.qr[:, J:, :] == np.array([1, 0, 0, 1])[None, :, None])
+    if model == "latent":
+        assert np.allclose(P.mean.beta, P.qr[3:, :5, :].mean(axis=(0, 2))) and np.all(P.qr[:, 0, :] == 0) and np.all(P.qr[:, 5, :] == 1)
+        assert not np.all(P.qr[:, 8, :] == 1)                                  # cov2one defaults to false for Latent
+    d = pkg.getDic(M)
+    assert np.isfinite(d.DIC) and np.isfinite(d.pD)

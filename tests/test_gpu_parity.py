@@ -15,7 +15,8 @@ import parity_util as pu
 
 pytestmark = pytest.mark.gpu
 
-MODELS = ["mlirt", "rtirt", "latentqr", "crossqr"]
+MODELS = ["mlirt", "rtirt", "latentqr", "crossqr", "null", "cross", "latent"]     # the last three: SURVEY.md 8(f).1 variants
+NO_INTERCEPT = ("crossqr", "cross", "null")    # their sample! methods have no `intercept` keyword
 
 
 def _cmp_items_cross(res):
@@ -38,8 +39,8 @@ def test_f64_traces_match_oracle(model):
 @pytest.mark.parametrize("model", MODELS)
 @pytest.mark.parametrize("kw", [dict(intercept=True), dict(onepl=True), dict(cov2one=False), dict(cov2one=True)])
 def test_f64_kwargs(model, kw):
-    if model == "crossqr" and "intercept" in kw:
-        pytest.skip("sample!(::GibbsRtIrtCrossQr) has no intercept kwarg")
+    if model in NO_INTERCEPT and "intercept" in kw:
+        pytest.skip("this model's sample! has no intercept kwarg")
     res = pu.run_pair(model, N=300, J=9, nsweeps=3 if model == "crossqr" else 6, precision="f64", **kw)
     assert pu.max_rel_err(res) < 1e-8
 
@@ -95,7 +96,7 @@ def test_teacher_forced(model, precision, tol):
     T, N, J = 8, 600, 11
     Y, logT, X, init, _ = pu.make_problem(model, N, J)
     L = pu.ge.load_package()._lib
-    cov2one = model != "latentqr"
+    cov2one = model not in ("latentqr", "latent")
     op = pu.OracleProblem(model, Y, logT, X, init, qRt=0.85, cov2one=cov2one)
     eng = L.Engine(model=pu.MODELS[model], n_item=J, n_subj=N, n_feat=0 if X is None else X.shape[1], n_iter=T, n_chain=1,
                    n_burnin=0, cov2one=int(cov2one), q_rt=0.85, seed=1234, precision={"f32": 0, "f64": 1}[precision], trace_mode=1)
@@ -104,7 +105,7 @@ def test_teacher_forced(model, precision, tol):
     floor = 1e-6 if precision == "f64" else 1e-2
     for t in range(T):
         st = {k: op.arr[v].copy() for k, v in names.items()}
-        if model in ("mlirt", "rtirt"):
+        if model not in ("crossqr", "latentqr"):
             st.pop("nu")
         if model == "crossqr" and t == 0:
             st.pop("nu")           # constructors leave nu unset; it is drawn first
@@ -126,7 +127,7 @@ def test_teacher_forced(model, precision, tol):
                 assert e.max() < tol, (model, t, k, e.max())
 
 
-@pytest.mark.parametrize("model", ["mlirt", "rtirt", "latentqr"])
+@pytest.mark.parametrize("model", ["mlirt", "rtirt", "latentqr", "null", "cross", "latent"])
 def test_f32_chain_stays_coupled(model):
     T = 60
     res = pu.run_pair(model, N=1500, J=20, nsweeps=T, precision="f32")

@@ -13,6 +13,8 @@ def _problem(model, seed=0):
     g = np.random.default_rng(seed + 100)
     st = dict(init)
     st.update(a=np.exp(g.normal(0, 0.3, J)), b=g.normal(0, 1, J))
+    if model == "cross":
+        st.update(rho=g.normal(0, 0.3, J))
     if model != "mlirt":
         st.update(lam=g.normal(3, 0.5, J), sig2t=np.exp(g.normal(-1, 0.3, J)), sigp=np.array([[1.3, 0.2], [0.2, 0.8]]))
     if model == "crossqr":
@@ -154,6 +156,58 @@ def test_beta_latentqr_is_the_stacked_least_squares_solution():   # getSubjCoeff
     want[0] = 0.0
     op.step(13, 1)
     assert np.allclose(op.arr["beta"], want, rtol=1e-8, atol=1e-10)
+
+
+def test_null_cross_latent_variant_moments():
+    """The non-quantile variants: drawSubjSpeedNull :119-127, drawSubjSpeedLatent :147-156,
+    drawSubjSpeedCross :179-187, drawItemIntensityCross :225-231, drawItemTimeResidualCross :267-273, drawSubjCorrCross :463-469,
+    drawSubjCoefficientsLatent :399-416 (1 added to EVERY element again), drawSubjCovarianceLatent :563-579,
+    drawSubjCovarianceNull :522-535."""
+    # ---- Null: prior N(0, 1) for zeta -- Sigp[2,2] is NOT used
+    op, Y, logT, X, st = _problem("null")
+    P = _P(op, Y, logT, X)
+    parV = 1 / (1 / 1.0 + np.sum(1 / P["s2"], axis=1))
+    parM = parV * (0.0 / 1.0 + np.sum((P["lam"] - logT) / P["s2"], axis=1))
+    m, v = op.moments(4, N, N)
+    assert np.allclose(m, parM, rtol=1e-12) and np.allclose(v, parV, rtol=1e-12)
+    eta = np.column_stack([op.arr["theta"], op.arr["zeta"]])
+    Psi, _ = op.moments(9, 4)
+    assert np.allclose(Psi.reshape(2, 2), eta.T @ eta + np.eye(2), rtol=1e-12)
+    # ---- Cross
+    op, Y, logT, X, st = _problem("cross")
+    P = _P(op, Y, logT, None)
+    s0 = P["Sigp"][1, 1]
+    parV = 1 / (1 / s0 + np.sum(1 / P["s2"], axis=1))
+    parM = parV * (0.0 / s0 + np.sum((P["lam"] - logT - P["th"] * P["rho"]) / P["s2"], axis=1))
+    m, v = op.moments(4, N, N)
+    assert np.allclose(m, parM, rtol=1e-12) and np.allclose(v, parV, rtol=1e-12)
+    mu, sd = logT.mean(), logT.std(ddof=1)
+    parV = 1 / (1 / sd ** 2 + np.sum(N / P["s2"], axis=0))
+    parM = parV * (mu / sd ** 2 + np.sum((logT + P["ze"] + P["th"] * P["rho"]) / P["s2"], axis=0))
+    m, v = op.moments(5, J, J)
+    assert np.allclose(m, parM, rtol=1e-12) and np.allclose(v, parV, rtol=1e-12)
+    sh, sc = op.moments(6, J, J)
+    assert np.allclose(sh, 1e-3 + N / 2) and np.allclose(sc, 1e-3 + np.sum((logT - P["lam"] + P["ze"] + P["th"] * P["rho"]) ** 2, axis=0) / 2, rtol=1e-12)
+    parV = 1 / (1 + np.sum(P["th"] ** 2 / P["s2"], axis=0))
+    parM = parV * (0.0 + np.sum(P["th"] * (P["lam"] - P["ze"] - logT) / P["s2"], axis=0))
+    m, v = op.moments(7, J, J)
+    assert np.allclose(m, parM, rtol=1e-12) and np.allclose(v, parV, rtol=1e-12)
+    # ---- Latent
+    op, Y, logT, X, st = _problem("latent")
+    P = _P(op, Y, logT, X)
+    x = np.column_stack([np.ones(N), X, op.arr["theta"]])
+    s0 = P["Sigp"][1, 1]
+    parV = 1 / (1 / s0 + np.sum(1 / P["s2"], axis=1))
+    parM = parV * ((x @ op.arr["beta"]) / s0 + np.sum((P["lam"] - logT) / P["s2"], axis=1))
+    m, v = op.moments(4, N, N)
+    assert np.allclose(m, parM, rtol=1e-12) and np.allclose(v, parV, rtol=1e-12)
+    invO = 1 / s0
+    bV = np.linalg.inv(1.0 + invO * (x.T @ x))
+    bM = bV @ (0.0 + x.T @ op.arr["zeta"] * invO)
+    m, v = op.moments(11, F + 2, (F + 2) ** 2)
+    assert np.allclose(m, bM, rtol=1e-9) and np.allclose(v.reshape(F + 2, F + 2, order="F"), bV, rtol=1e-9)
+    sc, _ = op.moments(12, 1)
+    assert np.allclose(sc[0], 1e-3 + np.sum((op.arr["zeta"] - x @ op.arr["beta"]) ** 2) / 2, rtol=1e-12)
 
 
 def test_loglik_matches_host_post_processing():
