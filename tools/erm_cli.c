@@ -4,8 +4,8 @@
  * style of setDataRtIrt (/root/reference/src/SimTools.jl:149-178), runs sample!'s loop on the GPU and prints posterior
  * summaries and recovery statistics.
  *
- *   erm_cli [--model mlirt|rtirt|crossqr|latentqr] [--nsubj N] [--nitem J] [--nfeat F] [--niter K] [--nchain C]
- *           [--seed S] [--precision f32|f64] [--device D] [--qrt Q]
+ *   erm_cli [--model mlirt|rtirt|crossqr|latentqr|null|cross|latent] [--nsubj N] [--nitem J] [--nfeat F] [--niter K] [--nchain C]
+ *           [--seed S] [--precision f32|f64]  [--device D] [--qrt Q] [--dry-run]
  *
  * Build: gcc -O2 -I include tools/erm_cli.c -L extendedrtirtmodeling.jl_amd -lertirt -lm -Wl,-rpath,'$ORIGIN/../extendedrtirtmodeling.jl_amd' -o tools/erm_cli
  */
@@ -26,7 +26,18 @@ static double unif(void)   /* splitmix64 -> (0,1) */
     return ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
 static double gauss(void) { return sqrt(-2.0 * log(unif())) * cos(6.283185307179586 * unif()); }
-static double pos_gauss(double m, double s) { double v; do v = m + s * gauss(); while (v <= 0.0); return v; }
+/* N(m, s) truncated to (0, inf): plain rejection near the bulk, Robert's (1995) exponential proposal in the tail (a rejection loop
+ * on the untruncated normal would spin ~1/Phi(m/s) times for a fast subject on a slow item) */
+static double pos_gauss(double m, double s)
+{
+    const double a = -m / s;                 /* standardised lower bound */
+    if (a < 0.5) { double v; do v = m + s * gauss(); while (v <= 0.0); return v; }
+    const double al = 0.5 * (a + sqrt(a * a + 4.0));
+    for (;;) {
+        const double z = a - log(unif()) / al;
+        if (unif() < exp(-0.5 * (z - al) * (z - al))) return m + s * z;
+    }
+}
 
 static double corr(const double* x, const double* y, long n)
 {
@@ -47,10 +58,11 @@ static double rmse(const double* x, const double* y, long n)
 
 int main(int argc, char** argv)
 {
-    const char* model = "rtirt"; const char* prec = "f32";
+    const char* model = "rtirt"; const char* prec = "f32"; int dry = 0;
     long N = 2000; int J = 15, F = 3, niter = 400, nchain = 1, device = 0; uint64_t seed = 1234; double qrt = 0.5;
     for (int k = 1; k < argc; ++k) {
         if (!strcmp(argv[k], "--version")) { printf("%s\n", erm_version()); return 0; }
+        if (!strcmp(argv[k], "--dry-run")) { dry = 1; continue; }        /* generate the data, print its summary, do not touch the GPU */
         if (!strcmp(argv[k], "--help") || k + 1 >= argc) { printf("usage: erm_cli [--model m] [--nsubj N] [--nitem J] [--nfeat F] [--niter K] [--nchain C] [--seed S] [--precision f32|f64] [--device D] [--qrt Q] | --version\n"); return !strcmp(argv[k], "--help") ? 0 : 1; }
         const char* v = argv[k + 1];
         if (!strcmp(argv[k], "--model")) model = v;
@@ -67,7 +79,8 @@ int main(int argc, char** argv)
         ++k;
     }
     int mid = !strcmp(model, "mlirt") ? ERM_MODEL_MLIRT : !strcmp(model, "rtirt") ? ERM_MODEL_RTIRT
-            : !strcmp(model, "crossqr") ? ERM_MODEL_CROSSQR : !strcmp(model, "latentqr") ? ERM_MODEL_LATENTQR : -1;
+            : !strcmp(model, "crossqr") ? ERM_MODEL_CROSSQR : !strcmp(model, "latentqr") ? ERM_MODEL_LATENTQR
+            : !strcmp(model, "null") ? ERM_MODEL_NULL : !strcmp(model, "cross") ? ERM_MODEL_CROSS : !strcmp(model, "latent") ? ERM_MODEL_LATENT : -1;
     if (mid < 0) { fprintf(stderr, "unknown model %s\n", model); return 1; }
     rng_state ^= seed;
 
@@ -78,7 +91,7 @@ int main(int argc, char** argv)
     double* theta = malloc(sizeof(double) * N), *zeta = malloc(sizeof(double) * N);
     uint8_t* Y = malloc((size_t)N * J); double* logT = malloc(sizeof(double) * N * J);
     for (int j = 0; j < J; ++j) { a[j] = pos_gauss(1.0, 0.2); b[j] = 0.5 * gauss(); lam[j] = pos_gauss(4.0, 0.2); sg[j] = exp(log(0.3) + 0.2 * gauss()); }
-    for (int f = 0; f < 2 * F; ++f) beta[f] = gauss();
+    for (int f = 0; f < 2 * F; ++f) beta[f] = (mid == ERM_MODEL_NULL) ? 0.0 : gauss();    /* the Null model has no covariate effects */
     for (long e = 0; e < N * F; ++e) X[e] = gauss();
     for (long i = 0; i < N; ++i) {
         double mt = 0, mz = 0;
@@ -92,11 +105,17 @@ int main(int argc, char** argv)
             logT[i + (long)j * N] = pos_gauss(lam[j] - zeta[i], sqrt(sg[j]));
         }
 
+    if (dry) {
+        double sy = 0, st = 0;
+        for (long e = 0; e < N * J; ++e) { sy += Y[e]; st += logT[e]; }
+        printf("dry run      mean(Y)=%.4f mean(logT)=%.4f\n", sy / (double)(N * J), st / (double)(N * J));
+        return 0;
+    }
     /* ---- the sample! path through the C ABI */
     erm_config cfg; memset(&cfg, 0, sizeof cfg);
-    cfg.model = mid; cfg.n_item = J; cfg.n_subj = N; cfg.n_feat = (mid == ERM_MODEL_CROSSQR) ? 0 : F; cfg.n_iter = niter; cfg.n_chain = nchain;
+    cfg.model = mid; cfg.n_item = J; cfg.n_subj = N; cfg.n_feat = (mid == ERM_MODEL_CROSSQR || mid == ERM_MODEL_CROSS) ? 0 : F; cfg.n_iter = niter; cfg.n_chain = nchain;
     cfg.n_burnin = (int)floor(niter / 2.0 + 0.5);
-    cfg.cov2one = (mid == ERM_MODEL_LATENTQR) ? 0 : 1; cfg.q_rt = qrt; cfg.seed = seed; cfg.device = device;
+    cfg.cov2one = (mid == ERM_MODEL_LATENTQR || mid == ERM_MODEL_LATENT) ? 0 : 1; cfg.q_rt = qrt; cfg.seed = seed; cfg.device = device;
     cfg.precision = !strcmp(prec, "f64") ? ERM_PREC_F64 : ERM_PREC_F32; cfg.trace_mode = ERM_TRACE_SUMMARY;
     erm_handle h = NULL;
     CHECK(erm_create(&cfg, &h));
