@@ -96,7 +96,8 @@ int main(int argc, char** argv)
     for (long i = 0; i < N; ++i) {
         double mt = 0, mz = 0;
         for (int f = 0; f < F; ++f) { mt += X[i + (long)f * N] * beta[f]; mz += X[i + (long)f * N] * beta[F + f]; }
-        theta[i] = mt + gauss(); zeta[i] = mz + gauss();
+        /* only MlIrt / RtIrt regress theta on X; the other models fix theta's scale at N(0, 1) (drawSubjAbilityNull) */
+        theta[i] = ((mid == ERM_MODEL_MLIRT || mid == ERM_MODEL_RTIRT) ? mt : 0.0) + gauss(); zeta[i] = mz + gauss();
     }
     for (int j = 0; j < J; ++j)
         for (long i = 0; i < N; ++i) {
