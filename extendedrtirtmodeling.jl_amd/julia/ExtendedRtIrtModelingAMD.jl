@@ -8,13 +8,17 @@
 #   sample!(::GibbsRtIrt)          src/GibbsRtIrt.pl.jl:278-346
 #   sample!(::GibbsRtIrtCrossQr)   src/GibbsRtIrtCross.pl.jl:265-325
 #   sample!(::GibbsRtIrtLatentQr)  src/GibbsRtIrtLatent.pl.jl:271-337
+#   sample!(::GibbsRtIrtNull)      src/GibbsRtIrt.pl.jl:367-426
+#   sample!(::GibbsRtIrtCross)     src/GibbsRtIrtCross.pl.jl:176-235
+#   sample!(::GibbsRtIrtLatent)    src/GibbsRtIrtLatent.pl.jl:168-233
 # Struct names, fields, constructor behaviour, kwargs, error text and the Post layout are the reference's; coef / precis /
 # getDic / comparePara / checkConvergence of the reference keep working on the filled `Post`.
 module ExtendedRtIrtModelingAMD
 
 using LinearAlgebra, Random
 
-export sample!, GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCrossQr, GibbsRtIrtLatentQr, GibbsRtIrtQuantile, libertirt_path!
+export sample!, GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCrossQr, GibbsRtIrtLatentQr, GibbsRtIrtQuantile, GibbsRtIrtNull, GibbsRtIrtCross,
+       GibbsRtIrtLatent, libertirt_path!
 
 const LIB = Ref{String}(get(ENV, "LIBERTIRT", "libertirt.so"))
 libertirt_path!(p::AbstractString) = (LIB[] = String(p))
@@ -31,6 +35,7 @@ struct ErmState
     beta::Ptr{Float64}; sigp::Ptr{Float64}; rho::Ptr{Float64}; nu::Ptr{Float64}
 end
 const MODEL_MLIRT, MODEL_RTIRT, MODEL_CROSSQR, MODEL_LATENTQR = Int32(0), Int32(1), Int32(2), Int32(3)
+const MODEL_NULL, MODEL_CROSS, MODEL_LATENT = Int32(4), Int32(5), Int32(6)
 const TRACE_RA, TRACE_RT, TRACE_QR, TRACE_LOGLIKE = Int32(0), Int32(1), Int32(2), Int32(3)
 
 lasterr() = unsafe_string(ccall((:erm_last_error, LIB[]), Cstring, ()))
@@ -47,7 +52,8 @@ mutable struct OutputPost
 end
 
 abstract type GibbsAMD end
-for (T, model) in ((:GibbsMlIrt, MODEL_MLIRT), (:GibbsRtIrt, MODEL_RTIRT), (:GibbsRtIrtCrossQr, MODEL_CROSSQR), (:GibbsRtIrtLatentQr, MODEL_LATENTQR))
+for (T, model) in ((:GibbsMlIrt, MODEL_MLIRT), (:GibbsRtIrt, MODEL_RTIRT), (:GibbsRtIrtCrossQr, MODEL_CROSSQR), (:GibbsRtIrtLatentQr, MODEL_LATENTQR),
+                   (:GibbsRtIrtNull, MODEL_NULL), (:GibbsRtIrtCross, MODEL_CROSS), (:GibbsRtIrtLatent, MODEL_LATENT))
     @eval begin
         mutable struct $T <: GibbsAMD
             Cond; Data; truePara; Para; Post
@@ -86,6 +92,23 @@ function setInitialValues(s::GibbsRtIrtLatentQr)
                        σ²t = ones(C.nItem), β = randn(C.nFeat + 2), Σp = Matrix{Float64}(I, 2, 2)); s
 end
 
+# src/GibbsRtIrt.pl.jl:159-170; src/GibbsRtIrtCross.pl.jl:85-96; src/GibbsRtIrtLatent.pl.jl:78-89
+function setInitialValues(s::GibbsRtIrtNull)
+    C = s.Cond
+    s.Para = InputPara(θ = randn(C.nSubj), a = ones(C.nItem), b = zeros(C.nItem), ζ = randn(C.nSubj), λ = zeros(C.nItem),
+                       σ²t = ones(C.nItem), Σp = Matrix{Float64}(I, 2, 2)); s
+end
+function setInitialValues(s::GibbsRtIrtCross)
+    C = s.Cond
+    s.Para = InputPara(θ = randn(C.nSubj), a = ones(C.nItem), b = zeros(C.nItem), ζ = randn(C.nSubj), λ = zeros(C.nItem),
+                       σ²t = ones(C.nItem), ρ = randn(C.nItem), Σp = Matrix{Float64}(I, 2, 2)); s
+end
+function setInitialValues(s::GibbsRtIrtLatent)
+    C = s.Cond
+    s.Para = InputPara(θ = randn(C.nSubj), a = ones(C.nItem), b = zeros(C.nItem), ζ = randn(C.nSubj), λ = zeros(C.nItem),
+                       σ²t = ones(C.nItem), β = randn(C.nFeat + 2), Σp = Matrix{Float64}(I, 2, 2)); s
+end
+
 dense(x) = isempty(x) ? Float64[] : Array{Float64}(x)
 ptr(x::Array{Float64}) = isempty(x) ? Ptr{Float64}(C_NULL) : pointer(x)
 
@@ -100,7 +123,7 @@ function engine!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool)
     check(ccall((:erm_create, LIB[]), Cint, (Ref{ErmConfig}, Ref{Ptr{Cvoid}}), cfg, h))
     Y = Array{UInt8}(M.Data.Y)                                  # Matrix{Bool} from setData* or a 0/1 numeric matrix
     logT = modelid(M) == MODEL_MLIRT ? Float64[] : dense(M.Data.logT)
-    X = (modelid(M) == MODEL_CROSSQR || C.nFeat == 0) ? Float64[] : dense(M.Data.X)
+    X = (modelid(M) in (MODEL_CROSSQR, MODEL_CROSS, MODEL_NULL) || C.nFeat == 0) ? Float64[] : dense(M.Data.X)
     GC.@preserve Y logT X check(ccall((:erm_set_data, LIB[]), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}), h[], Y, ptr(logT), ptr(X)))
     M.handle, M.key = h[], key
     return M.handle
@@ -117,7 +140,7 @@ Same contract as the reference's `sample!`: runs `Cond.nIter * Cond.nChain` swee
 `MCMC.Post.{ra,rt,qr,logLike,mean}`, leaves the final state in `MCMC.Para`, returns `MCMC`.
 """
 function sample!(M::GibbsAMD; intercept = false, itemtype::Union{String} = "2pl",
-                 cov2one = !(M isa GibbsRtIrtLatentQr))
+                 cov2one = !(M isa GibbsRtIrtLatentQr || M isa GibbsRtIrtLatent))
     if !(itemtype in ["1pl", "2pl"])
         error("Invalid input: the item type must be '1pl' or '2pl'.")
     end
@@ -143,13 +166,14 @@ function sample!(M::GibbsAMD; intercept = false, itemtype::Union{String} = "2pl"
     modelid(M) != MODEL_CROSSQR && (Post.qr = trace(TRACE_QR))   # CrossQr: only the running mean of nu is kept on the device
 
     N, J, F = C.nSubj, C.nItem, C.nFeat
-    nb = modelid(M) == MODEL_MLIRT ? F + 1 : modelid(M) == MODEL_RTIRT ? 2 * (F + 1) : modelid(M) == MODEL_LATENTQR ? F + 2 : 0
+    nb = modelid(M) == MODEL_MLIRT ? F + 1 : modelid(M) in (MODEL_RTIRT, MODEL_NULL) ? 2 * (F + 1) : modelid(M) in (MODEL_LATENTQR, MODEL_LATENT) ? F + 2 : 0
     nnu = modelid(M) == MODEL_LATENTQR ? N : modelid(M) == MODEL_CROSSQR ? N * J : 0
     bufs = (zeros(N), zeros(J), zeros(J), zeros(N), zeros(J), zeros(J), zeros(nb), zeros(4), zeros(J), zeros(nnu))
     GC.@preserve bufs begin
         check(ccall((:erm_get_mean, LIB[]), Cint, (Ptr{Cvoid}, Ref{ErmState}), h, ErmState(map(ptr, bufs)...)))
     end
-    Post.mean = InputPara(θ = bufs[1], a = bufs[2], b = bufs[3], ζ = bufs[4], λ = bufs[5], σ²t = bufs[6], β = bufs[7], Σp = bufs[8], ρ = bufs[9], ν = bufs[10])
+    Post.mean = InputPara(θ = copy(bufs[1]), a = copy(bufs[2]), b = copy(bufs[3]), ζ = copy(bufs[4]), λ = copy(bufs[5]), σ²t = copy(bufs[6]),
+                          β = copy(bufs[7]), Σp = copy(bufs[8]), ρ = copy(bufs[9]), ν = copy(bufs[10]))   # bufs are reused below
     GC.@preserve bufs begin
         check(ccall((:erm_get_state, LIB[]), Cint, (Ptr{Cvoid}, Ref{ErmState}), h, ErmState(map(ptr, bufs)...)))
     end
@@ -158,8 +182,9 @@ function sample!(M::GibbsAMD; intercept = false, itemtype::Union{String} = "2pl"
     if modelid(M) != MODEL_MLIRT
         P.ζ, P.λ, P.σ²t, P.Σp = copy(bufs[4]), copy(bufs[5]), copy(bufs[6]), reshape(copy(bufs[8]), 2, 2)
     end
-    nb > 0 && (P.β = modelid(M) == MODEL_RTIRT ? reshape(copy(bufs[7]), F + 1, 2) : copy(bufs[7]))
-    modelid(M) == MODEL_CROSSQR && (P.ρ = copy(bufs[9]); P.ν = reshape(copy(bufs[10]), N, J))
+    nb > 0 && (P.β = modelid(M) in (MODEL_RTIRT, MODEL_NULL) ? reshape(copy(bufs[7]), F + 1, 2) : copy(bufs[7]))
+    modelid(M) in (MODEL_CROSSQR, MODEL_CROSS) && (P.ρ = copy(bufs[9]))
+    modelid(M) == MODEL_CROSSQR && (P.ν = reshape(copy(bufs[10]), N, J))
     modelid(M) == MODEL_LATENTQR && (P.ν = copy(bufs[10]))
     return M
 end
