@@ -71,7 +71,7 @@ template <typename real> struct PassArgs {
     const double* par; const double* cst; double* slab; const Ctl* ctl;
     double* gslab; unsigned int* gcnt;              // per-group reduced slabs and arrival counters (GROUP consecutive workgroups)
     double* sum_theta; double* sum_zeta; double* sum_nu;
-    real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] or nullptr
+    real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] (CrossQr's tr_nu: [rows][N][J]) or nullptr
     long long N; long long rows_per_block;          // each workgroup owns rows [b*rpb, (b+1)*rpb)
     int rows_per_wave;                              // capacity of a wave's theta cache: ceil(rpb / nWaves)
     int J; int nFeat; int W; int logW; int IPL;
@@ -499,6 +499,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                         const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
                         llc += (double)(real(-0.5) * ((real)LOG_2PI + lsig + r_log(var_) + r_div(er * er * isig, var_)));
                         if (has_nu(MODEL) && post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
+                        if (has_nu(MODEL) && A.tr_nu) A.tr_nu[(size_t)trow * (size_t)A.N * J + e] = nu;     // Post.qr's vec(nu_t) (src/GibbsRtIrtCross.pl.jl:296)
                     }
                     const real den = r_div(r_sqrt(k2), r_sqrt(isig));            // sqrt(sig2t k2)
                     const real parA = r_div(r_abs(c - lamc + ze + th * rho), den);

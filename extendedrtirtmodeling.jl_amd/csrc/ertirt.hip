@@ -227,6 +227,14 @@ template <typename real> struct Engine : EngineBase {
             rc |= dTrTheta.alloc((size_t)rows_cap * N * sizeof(real));
             if (is_rt()) rc |= dTrZeta.alloc((size_t)rows_cap * N * sizeof(real));
             if (cfg.model == ERM_MODEL_LATENTQR) rc |= dTrNu.alloc((size_t)rows_cap * N * sizeof(real));
+            if (cfg.model == ERM_MODEL_CROSSQR) {
+                // Post.qr of GibbsRtIrtCrossQr carries vec(nu) (N*J values) per sweep (src/GibbsRtIrtCross.pl.jl:65,296): kept on the device
+                // when it fits the budget (ERM_NU_TRACE_MAX_GB, default 16), otherwise only nu's running mean is available
+                const char* e = getenv("ERM_NU_TRACE_MAX_GB");
+                const double cap_gb = e ? atof(e) : 16.0;
+                const double need_gb = (double)rows_cap * (double)NJ * sizeof(real) / 1073741824.0;
+                if (need_gb <= cap_gb) rc |= dTrNu.alloc((size_t)rows_cap * NJ * sizeof(real));
+            }
         }
         if (rc) return rc;
         if (cfg.profile) {
@@ -627,8 +635,8 @@ template <typename real> struct Engine : EngineBase {
             return 0;
         }
         if (cfg.trace_mode != ERM_TRACE_FULL) return fail(ERM_ERR_NOTRACE, "subject-level traces need trace_mode = ERM_TRACE_FULL");
-        if (which == ERM_TRACE_QR && cfg.model == ERM_MODEL_CROSSQR)
-            return fail(ERM_ERR_NOTRACE, "CrossQr keeps only the running mean of nu (N*J values per sweep are not stored); use erm_get_item_trace + erm_get_mean");
+        if (which == ERM_TRACE_QR && cfg.model == ERM_MODEL_CROSSQR && !dTrNu.p)
+            return fail(ERM_ERR_NOTRACE, "the per-sweep nu trace (N*J values per sweep) exceeds ERM_NU_TRACE_MAX_GB; use erm_get_item_trace (rho, Sigp) + erm_get_mean (nu)");
         std::vector<double> it;
         if (int rc = fetch_item_trace(it)) return rc;
         const int64_t wi = item_trace_width();
@@ -655,6 +663,13 @@ template <typename real> struct Engine : EngineBase {
             }
             for (int64_t r = 0; r < rows_cap; ++r) for (int k = 0; k < q; ++k) at(r, k) = it[r * wi + 4 * J + k];
             if (cfg.model == ERM_MODEL_LATENTQR) if (int rc = subj(dTrNu, q)) return rc;
+            if (cfg.model == ERM_MODEL_CROSSQR) {       // vec(nu): column-major N x J after [rho; vec(Sigp)]
+                std::vector<real> cells((size_t)N * J);
+                for (int64_t r = 0; r < rows_cap; ++r) {
+                    HIPCHK(hipMemcpy(cells.data(), dTrNu.as<real>() + (size_t)r * N * J, cells.size() * sizeof(real), hipMemcpyDeviceToHost));
+                    for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) at(r, q + i + N * j) = (double)cells[(size_t)i * J + j];
+                }
+            }
         }
         return 0;
     }

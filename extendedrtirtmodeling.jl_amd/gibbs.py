@@ -111,8 +111,14 @@ class _GibbsBase:
             Post.ra = eng.trace(_lib.TRACE_RA)
             if self._model != _lib.MODEL_MLIRT:
                 Post.rt = eng.trace(_lib.TRACE_RT)
-            if self._model != _lib.MODEL_CROSSQR:
+            try:
                 Post.qr = eng.trace(_lib.TRACE_QR)
+            except _lib.ErmError:
+                if self._model != _lib.MODEL_CROSSQR:
+                    raise
+                # vec(nu) per sweep did not fit the device budget: Post.qr keeps [rho; vec(Sigp)] (the reference's first nItem+4 columns)
+                it = eng.item_trace()
+                Post.qr = np.asfortranarray(it[:, 4 * C.nItem:].reshape(C.nIter, C.nChain, -1).transpose(0, 2, 1))
         Post.item_trace = eng.item_trace()
         m = eng.get_mean()
         mean = InputPara(theta=m["theta"], a=m["a"], b=m["b"])

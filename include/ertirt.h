@@ -100,7 +100,8 @@ int64_t erm_rows_done(erm_handle h);
 int erm_reset_trace(erm_handle h);   /* forget recorded rows and running means (state is kept) */
 
 /* Post.ra / Post.rt / Post.qr / Post.logLike (src/GibbsRtIrt.pl.jl:35-71; Cross :55-69; Latent :50-64) in Julia layout
- * [nIter][width][nChain], nIter fastest.  Needs ERM_TRACE_FULL for RA/RT/QR. */
+ * [nIter][width][nChain], nIter fastest.  Needs ERM_TRACE_FULL for RA/RT/QR.  GibbsRtIrtCrossQr's qr carries vec(nu) (nSubj*nItem values per
+ * sweep); it is recorded when nIter*nChain*nSubj*nItem values fit ERM_NU_TRACE_MAX_GB (environment, default 16), else ERM_ERR_NOTRACE. */
 int64_t erm_trace_width(erm_handle h, int which);
 int erm_get_trace(erm_handle h, int which, double* out);
 /* item-level trace, always kept: out[row][4*nItem + nq] = a, b, lambda, sig2t, small part of qr (row-major) */

@@ -173,8 +173,7 @@ def run_device(model, Y, logT, X, init, nsweeps, *, precision="f64", qRt=0.85, s
         out["ra"] = eng.trace(L.TRACE_RA)
         if model != "mlirt":
             out["rt"] = eng.trace(L.TRACE_RT)
-        if model != "crossqr":
-            out["qr"] = eng.trace(L.TRACE_QR)
+        out["qr"] = eng.trace(L.TRACE_QR)
     return out
 
 
@@ -187,14 +186,13 @@ def run_pair(model, N, J, nsweeps, *, F=3, precision="f64", seed=7, qRt=0.85, **
     dev = run_device(model, Y, logT, X, init, nsweeps, precision=precision, qRt=qRt, **kw)
     op = OracleProblem(model, Y, logT, X, init, qRt=qRt, intercept=kw.get("intercept", False), onepl=kw.get("onepl", False),
                        cov2one=cov2one, seed=kw.get("seed", 1234))
-    orc = op.run(nsweeps, with_nu=(model == "latentqr"))
+    orc = op.run(nsweeps, with_nu=(model in ("latentqr", "crossqr")))
     d = dict(orc=orc, dev=dev, model=model)
     # device traces in Julia layout (nIter, width, nChain=1) -> rows x width
     d["dev_ra"] = dev["ra"][:, :, 0]
     if model != "mlirt":
         d["dev_rt"] = dev["rt"][:, :, 0]
-    if model != "crossqr":
-        d["dev_qr"] = dev["qr"][:, :, 0]
+    d["dev_qr"] = dev["qr"][:, :, 0]
     d["dev_ll"] = dev["ll"][:, 0, 0]
     return d
 
@@ -208,10 +206,6 @@ def max_rel_err(res, floor=1e-6):
     e = [rel_err(res["dev_ra"], res["orc"]["ra"], floor).max()]
     if res["model"] != "mlirt":
         e.append(rel_err(res["dev_rt"], res["orc"]["rt"], floor).max())
-    if res["model"] != "crossqr":
-        e.append(rel_err(res["dev_qr"], res["orc"]["qr"], floor).max())
-    else:
-        J = res["orc"]["qr"].shape[1] - 4
-        e.append(rel_err(res["dev"]["item"][:, 4 * J:], res["orc"]["qr"], floor).max())
+    e.append(rel_err(res["dev_qr"], res["orc"]["qr"], floor).max())
     e.append(rel_err(res["dev_ll"], res["orc"]["ll"], floor).max())
     return float(max(e))

@@ -17,8 +17,8 @@ def test_engine_reproduces_golden_traces(model):
     assert pu.rel_err(dev["ra"][:, :, 0], z["ra"][:T]).max() < 1e-8
     if model != "mlirt":
         assert pu.rel_err(dev["rt"][:, :, 0], z["rt"][:T]).max() < 1e-8
-    if model != "crossqr":
-        assert pu.rel_err(dev["qr"][:, :, 0], z["qr"][:T]).max() < 1e-8
+    wq = z["qr"].shape[1]              # CrossQr's golden holds [rho; vec(Sigp)]; the device row continues with vec(nu)
+    assert pu.rel_err(dev["qr"][:, :wq, 0], z["qr"][:T]).max() < 1e-8
     assert pu.rel_err(dev["ll"][:, 0, 0], z["ll"][:T]).max() < 1e-8
 
 
@@ -74,3 +74,19 @@ def test_variant_samplers_fill_post_like_the_reference(name, model):
         assert not np.all(P.qr[:, 8, :] == 1)                                  # cov2one defaults to false for Latent
     d = pkg.getDic(M)
     assert np.isfinite(d.DIC) and np.isfinite(d.pD)
+
+
+def test_crossqr_post_qr_carries_rho_sigp_and_vec_nu():
+    """Post.qr of GibbsRtIrtCrossQr is [rho; vec(Sigp); vec(nu)] per sweep (src/GibbsRtIrtCross.pl.jl:65,296); Post.mean.nu is its
+    post-burn-in average reshaped N x J (column-major vec)."""
+    pkg = pu.ge.load_package()
+    z, Y, logT, X, init = load_golden("crossqr")
+    N, J = Y.shape
+    Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=0, nIter=6, nChain=1, qRt=0.85)
+    M = pkg.GibbsRtIrtCrossQr(Cond, Data=pkg.InputData(Y=Y, T=np.exp(logT), X=np.zeros((N, 0))), precision="f64")
+    pkg.sample_b(M)
+    P = M.Post
+    assert P.qr.shape == (6, J + 4 + N * J, 1)
+    assert np.all(P.qr[:, J + 4:, 0] > 0)
+    assert np.allclose(np.asarray(P.mean.nu).reshape(-1, order="F"), P.qr[3:, J + 4:, 0].mean(axis=0), rtol=1e-12)
+    assert np.allclose(P.mean.rho, P.qr[3:, :J, 0].mean(axis=0))
