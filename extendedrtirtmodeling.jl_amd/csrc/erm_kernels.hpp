@@ -76,6 +76,7 @@ template <typename real> struct PassArgs {
     int rows_per_wave;                              // capacity of a wave's theta cache: ceil(rpb / nWaves)
     int J; int nFeat; int W; int logW; int IPL;
     int mode;             // 0 = prologue (no theta/zeta draws, no LL, no trace), 1 = full sweep pass
+    int ngx;              // extra global statistics inserted before the log-likelihood slot (LatentQr sigp_mode 1: the 1/nu-weighted Gram entries)
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // diagnostics only: skip everything after stage k (0 = run everything)
 };
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     constexpr int NSTAT = ST::NSTAT;
     const int J = A.J, W = A.W, R = 64 / W, IPL = A.IPL;
     const int F = A.nFeat, p = F + 1;                // design [1 X]
-    const int NG = ST::ng(p);
+    const int NG = ST::ng(p) + A.ngx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
     const int s = lane & (W - 1), r = lane >> A.logW;
 
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 return nud;
             };
             for (int g = 0; g < NG - 1; ++g) {
-                int ca = 0, cb2 = 0;
+                int ca = 0, cb2 = 0; double wgt = 1.0;
                 if (MODEL == MLIRT) { ca = g; cb2 = cT; }
                 else if (fam_rt(MODEL)) {
                     if (g < p) { ca = g; cb2 = cT; }
@@ -369,9 +370,19 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     else if (g == 2 * p + 3) { ca = 0; cb2 = cN; }
                     else if (g == 2 * p + 4) { ca = cN; cb2 = cN; }
                     else if (g == 2 * p + 5) { ca = 0; cb2 = cZ; }
-                    else { ca = cZ; cb2 = cZ; }
+                    else if (g == 2 * p + 6) { ca = cZ; cb2 = cZ; }
+                    else {
+                        // sigp_mode 1: entries of x~' W x~ (upper triangle, row-major), x~' W u, u' W u with x~ = [1 X theta], W = diag(1/nu_{t+1})
+                        const int q = p + 1, ntri = q * (q + 1) / 2;
+                        int e = g - (2 * p + 7);
+                        auto col = [&](int u) { return u < p ? u : cT; };
+                        if (e < ntri) { int u = 0; while (e >= q - u) { e -= q - u; ++u; } ca = col(u); cb2 = col(u + e); }
+                        else if (e < ntri + q) { ca = col(e - ntri); cb2 = cU; }
+                        else { ca = cU; cb2 = cU; }
+                        wgt = 1.0 / nud;
+                    }
                 } else { ca = cZ; cb2 = cZ; }      // CrossQr pass B: sum zeta^2
-                double v = rok ? val(ca) * val(cb2) : 0.0;
+                double v = rok ? val(ca) * val(cb2) * wgt : 0.0;
                 v = bfly_sum(v, 1, 64);
                 if (lane == 0) gtot[g] += v;
             }
@@ -587,6 +598,7 @@ struct TinyArgs {
     int intercept, onepl, cov2one, sigp_mode;
     uint32_t chain; uint64_t seed; double k1, k2;
     int nq;               // number of small qr entries recorded per sweep
+    int ngx;              // extra global statistics of slab0 (see PassArgs::ngx)
     int dbg_stop;         // diagnostics only: return after stage k (0 = run everything)
 };
 
@@ -633,7 +645,7 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     const int J = T.J, p = T.nFeat + 1;
     const double Nd = (double)T.N;
     constexpr int NSTAT0 = Stats<MODEL, 0>::NSTAT;
-    const int NG0 = Stats<MODEL, 0>::ng(p);
+    const int NG0 = Stats<MODEL, 0>::ng(p) + T.ngx;
     const int NS0 = NSTAT0 * J + NG0;
     constexpr int NSTAT1 = fam_cq(MODEL) ? Stats<CROSSQR, 1>::NSTAT : 0;
     const int NG1 = fam_cq(MODEL) ? 2 : 0;
@@ -968,7 +980,18 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
             for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
             sr2 += bn[p] * bn[p] * tt;
             const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
-            const double parB = 1e-3 + sr2 * sw / sw2 + snu;
+            double quirk = sr2 * sw / sw2;
+            if (T.sigp_mode == 1) {
+                // the evidently intended sum_i r_i^2 / (2 k2 nu_i), r = u - x~ beta, from the 1/nu-weighted Gram statistics
+                const int q = p + 1, ntri = q * (q + 1) / 2;
+                const double* Wg = G0 + 2 * p + 7;
+                double sw_r2 = Wg[ntri + q];
+                for (int u = 0; u < q; ++u) sw_r2 -= 2.0 * bn[u] * Wg[ntri + u];
+                int e = 0;
+                for (int u = 0; u < q; ++u) for (int v = u; v < q; ++v, ++e) sw_r2 += (u == v ? 1.0 : 2.0) * bn[u] * Wg[e] * bn[v];
+                quirk = sw_r2 / (2.0 * T.k2);
+            }
+            const double parB = 1e-3 + quirk + snu;
             S[3] = parB / spd[0];
         } else {
             // drawSubjCovarianceCross src/Draw.pl.jl:542-557

@@ -139,7 +139,13 @@ template <typename real> struct Engine : EngineBase {
         const int pp = p();
         int ng = pp + 1;
         if (fam_rt(cfg.model)) ng = 2 * pp + 4; else if (fam_lq(cfg.model)) ng = 2 * pp + 8; else if (m_cq()) ng = phase == 0 ? 1 : 2;
-        return nstat(phase) * J + ng;
+        return nstat(phase) * J + ng + ngx();
+    }
+    // LatentQr with sigp_mode 1 also accumulates the 1/nu-weighted Gram entries of [1 X theta | u]
+    int ngx() const {
+        if (cfg.model != ERM_MODEL_LATENTQR || cfg.sigp_mode != 1) return 0;
+        const int q = p() + 1;
+        return q * (q + 1) / 2 + q + 1;
     }
     size_t pass_lds(int phase, int nWaves) const {
         const int ng = stat_sizes(phase) - nstat(phase) * J;
@@ -158,7 +164,7 @@ template <typename real> struct Engine : EngineBase {
         if (m_nu() && !(cfg.q_rt > 0.0 && cfg.q_rt < 1.0))
             return fail(ERM_ERR_ARG, "qRt must be between 0 and 1");   // @assert at src/Draw.pl.jl:476
         if (cfg.n_iter < 0 || cfg.n_chain < 1 || cfg.n_burnin < 0) return fail(ERM_ERR_ARG, "bad n_iter / n_chain / n_burnin");
-        if (cfg.sigp_mode != 0) return fail(ERM_ERR_ARG, "sigp_mode 1 is reserved");
+        if (cfg.sigp_mode != 0 && cfg.sigp_mode != 1) return fail(ERM_ERR_ARG, "sigp_mode must be 0 or 1");
         HIPCHK(hipSetDevice(cfg.device));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
@@ -292,7 +298,7 @@ template <typename real> struct Engine : EngineBase {
         a.ctl = dCtl.as<Ctl>();
         a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
         a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
-        a.N = N; a.rows_per_block = rows_per_block; a.rows_per_wave = rows_per_wave; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode;
+        a.N = N; a.rows_per_block = rows_per_block; a.rows_per_wave = rows_per_wave; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode; a.ngx = phase == 0 ? ngx() : 0;
         a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
@@ -311,7 +317,7 @@ template <typename real> struct Engine : EngineBase {
         const double q = cfg.q_rt;
         t.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); t.k2 = 2.0 / (q * (1.0 - q));
         if (!m_nu()) { t.k1 = 0.0; t.k2 = 1.0; }
-        t.nq = nq();
+        t.nq = nq(); t.ngx = ngx();
         { const char* e = getenv("ERM_TINY_STOP"); t.dbg_stop = e ? atoi(e) : 0; }
         return t;
     }

@@ -49,7 +49,7 @@ typedef struct {
     int32_t intercept;      /* sample!(...; intercept=false) */
     int32_t one_pl;         /* itemtype == "1pl" */
     int32_t cov2one;        /* sample!(...; cov2one) */
-    int32_t sigp_mode;      /* LatentQr Sigma_p scale: 0 = reference expression src/Draw.pl.jl:594 (closed form), 1 = reserved */
+    int32_t sigp_mode;      /* LatentQr Sigma_p scale: 0 = reference expression src/Draw.pl.jl:594 (the N x N `/` in closed form), 1 = the evidently intended sum r_i^2/(2 k2 nu_i) */
     int32_t chain_id;       /* selects an independent random stream (one chain per GPU farms use the rank) */
     double  q_rt;           /* Cond.qRt */
     uint64_t seed;

@@ -71,14 +71,14 @@ def orc_sample(which, n, par0=None, par1=None, *, seed=1234, site=15, sweep=1):
 class OracleProblem:
     """Holds data + state arrays (column-major, fp64) in the oracle's structs."""
 
-    def __init__(self, model, Y, logT, X, state, *, qRt=0.5, intercept=False, onepl=False, cov2one=True, seed=1234, chain=0):
+    def __init__(self, model, Y, logT, X, state, *, qRt=0.5, intercept=False, onepl=False, cov2one=True, seed=1234, chain=0, sigp_mode=0):
         self.model = MODELS[model] if isinstance(model, str) else model
         self.N, self.J = Y.shape
         self.F = 0 if X is None else X.shape[1]
         self.Y = np.asfortranarray(Y.astype(np.uint8))
         self.logT = None if logT is None else np.asfortranarray(logT, dtype=np.float64)
         self.X = None if X is None else np.asfortranarray(X, dtype=np.float64)
-        self.cfg = orc_config(self.model, self.J, self.N, self.F, int(intercept), int(onepl), int(cov2one), chain, 0, qRt, seed)
+        self.cfg = orc_config(self.model, self.J, self.N, self.F, int(intercept), int(onepl), int(cov2one), chain, int(sigp_mode), qRt, seed)
         self.data = orc_data(self.Y.ctypes.data, None if self.logT is None else self.logT.ctypes.data,
                              None if self.X is None else self.X.ctypes.data)
         N, J, F = self.N, self.J, self.F
@@ -185,7 +185,7 @@ def run_pair(model, N, J, nsweeps, *, F=3, precision="f64", seed=7, qRt=0.85, **
         cov2one = model not in ("latentqr", "latent")
     dev = run_device(model, Y, logT, X, init, nsweeps, precision=precision, qRt=qRt, **kw)
     op = OracleProblem(model, Y, logT, X, init, qRt=qRt, intercept=kw.get("intercept", False), onepl=kw.get("onepl", False),
-                       cov2one=cov2one, seed=kw.get("seed", 1234))
+                       cov2one=cov2one, seed=kw.get("seed", 1234), sigp_mode=kw.get("sigp_mode", 0))
     orc = op.run(nsweeps, with_nu=(model in ("latentqr", "crossqr")))
     d = dict(orc=orc, dev=dev, model=model)
     # device traces in Julia layout (nIter, width, nChain=1) -> rows x width

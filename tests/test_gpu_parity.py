@@ -47,6 +47,16 @@ def test_f64_geometry_invariance(model, W):
     assert pu.max_rel_err(res) < 1e-8
 
 
+@pytest.mark.parametrize("F", [0, 3, 6])
+def test_latentqr_intended_sigp_scale(F):
+    """sigp_mode = 1: the evidently intended sum r_i^2/(2 k2 nu_i) of drawSubjCovarianceLatentQr (src/Draw.pl.jl:594 evaluates an
+    N x N matrix division instead -- mode 0); on the device it needs the 1/nu-weighted Gram statistics of [1 X theta | u]."""
+    res = pu.run_pair("latentqr", N=500, J=9, nsweeps=8, F=F, precision="f64", sigp_mode=1)
+    assert pu.max_rel_err(res) < 1e-8
+    ref = pu.run_pair("latentqr", N=500, J=9, nsweeps=8, F=F, precision="f64", sigp_mode=0)
+    assert not np.allclose(res["dev_qr"][:, F + 2 + 3], ref["dev_qr"][:, F + 2 + 3])        # Sigp[2,2] differs between the modes
+
+
 @pytest.mark.parametrize("J,N", [(1, 50), (64, 130), (65, 70), (130, 40)])
 def test_f64_ragged_shapes(J, N):
     res = pu.run_pair("rtirt", N=N, J=J, nsweeps=4, precision="f64")
