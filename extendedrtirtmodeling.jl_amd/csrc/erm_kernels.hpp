@@ -139,6 +139,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
     real* sh_th = sh_item + NITEMARR * J + (size_t)wave * 4 * A.rows_per_wave;   // theta_t of this wave's subjects
     real* sh_rs = sh_th + A.rows_per_wave;                                         // [rows_per_wave][3] row sums
+    const int NV = A.nFeat + 4;
+    real* sh_val = sh_item + NITEMARR * J + (size_t)nWaves * 4 * A.rows_per_wave;   // [rows_per_block][NV] per-subject values of the global statistics
 
     const uint8_t* __restrict__ gY = A.Y;
     const real* __restrict__ gC = A.C;
@@ -174,7 +176,6 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     const double sp_c0 = -LOG_2PI - 0.5 * log(sp_det);
     const double sp_q00 = sh_struct[3] / sp_det, sp_q01 = -(sh_struct[1] + sh_struct[2]) / sp_det, sp_q11 = sh_struct[0] / sp_det;
     double* acc = sh_acc + (size_t)wave * NSTAT * J;
-    double* gtot = sh_gacc + (size_t)wave * NG;
     double ll = 0.0;
 
     const long long row0 = (long long)blockIdx.x * A.rows_per_block;
@@ -338,54 +339,13 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         }
         if (PHASE == 0 && rok) sh_th[li] = th;
 
-        // ---- global statistics for the next tiny step: each is a sum over subjects of a product of two per-subject values;
-        // summed over the 64 subjects of this trip by a wave butterfly (fixed order), then accumulated by lane 0.
-        // value codes: 0 -> 1, 1..F -> X columns, F+1 theta, F+2 zeta, F+3 u = zeta - k1 nu_{t+1}, F+4 nu_{t+1}
-        if (NG > 1) {
-            const int cT = F + 1, cZ = F + 2, cU = F + 3, cN = F + 4;
-            const double thd = (double)th, zed = (double)ze, nud = (double)nu_next, upd = zed - (double)k1 * nud;
-            auto val = [&](int code) -> double {
-                if (code == 0) return 1.0;
-                if (code <= F) return (double)xcol(code);
-                if (code == cT) return thd;
-                if (code == cZ) return zed;
-                if (code == cU) return upd;
-                return nud;
-            };
-            for (int g = 0; g < NG - 1; ++g) {
-                int ca = 0, cb2 = 0; double wgt = 1.0;
-                if (MODEL == MLIRT) { ca = g; cb2 = cT; }
-                else if (fam_rt(MODEL)) {
-                    if (g < p) { ca = g; cb2 = cT; }
-                    else if (g < 2 * p) { ca = g - p; cb2 = cZ; }
-                    else if (g == 2 * p) { ca = cT; cb2 = cT; }
-                    else if (g == 2 * p + 1) { ca = cT; cb2 = cZ; }
-                    else { ca = cZ; cb2 = cZ; }
-                } else if (fam_lq(MODEL)) {
-                    if (g < p) { ca = g; cb2 = cT; }
-                    else if (g == p) { ca = cT; cb2 = cT; }
-                    else if (g < 2 * p + 1) { ca = g - p - 1; cb2 = cU; }
-                    else if (g == 2 * p + 1) { ca = cT; cb2 = cU; }
-                    else if (g == 2 * p + 2) { ca = cU; cb2 = cU; }
-                    else if (g == 2 * p + 3) { ca = 0; cb2 = cN; }
-                    else if (g == 2 * p + 4) { ca = cN; cb2 = cN; }
-                    else if (g == 2 * p + 5) { ca = 0; cb2 = cZ; }
-                    else if (g == 2 * p + 6) { ca = cZ; cb2 = cZ; }
-                    else {
-                        // sigp_mode 1: entries of x~' W x~ (upper triangle, row-major), x~' W u, u' W u with x~ = [1 X theta], W = diag(1/nu_{t+1})
-                        const int q = p + 1, ntri = q * (q + 1) / 2;
-                        int e = g - (2 * p + 7);
-                        auto col = [&](int u) { return u < p ? u : cT; };
-                        if (e < ntri) { int u = 0; while (e >= q - u) { e -= q - u; ++u; } ca = col(u); cb2 = col(u + e); }
-                        else if (e < ntri + q) { ca = col(e - ntri); cb2 = cU; }
-                        else { ca = cU; cb2 = cU; }
-                        wgt = 1.0 / nud;
-                    }
-                } else { ca = cZ; cb2 = cZ; }      // CrossQr pass B: sum zeta^2
-                double v = rok ? val(ca) * val(cb2) * wgt : 0.0;
-                v = bfly_sum(v, 1, 64);
-                if (lane == 0) gtot[g] += v;
-            }
+        // ---- per-subject values of the global statistics (sums over subjects of products of two of them), parked in LDS and reduced
+        // by the whole workgroup after the barrier below (a 64-lane fp64 butterfly per statistic here cost 6 us of the pass):
+        // slot c-1 holds value code c: 1..F -> X columns, F+1 theta, F+2 zeta, F+3 u = zeta - k1 nu_{t+1}, F+4 nu_{t+1}
+        if (NG > 1 && rok) {
+            real* o = sh_val + (size_t)(i - row0) * NV;
+            for (int u = 1; u <= F; ++u) o[u - 1] = xcol(u);
+            o[F] = th; o[F + 1] = ze; o[F + 2] = ze - k1 * nu_next; o[F + 3] = nu_next;
         }
     }
     if (A.dbg_stop == 2) return;
@@ -443,6 +403,52 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     }
     if (A.dbg_stop == 3) return;
     __syncthreads();
+
+    // ---- global statistics for the next tiny step: statistic g = sum over the workgroup's subjects of va * vb (* 1/nu for the
+    // sigp_mode-1 block); 32 lanes per statistic, lane l sums subjects l, l+32, ... in order, then a 32-lane butterfly: fixed order
+    if (NG > 1) {
+        const int cT = F + 1, cZ = F + 2, cU = F + 3, cN = F + 4;
+        const int tg = threadIdx.x >> 5, tl = threadIdx.x & 31, ngrp = blockDim.x >> 5;
+        for (int g = tg; g < NG - 1; g += ngrp) {
+            int ca = 0, cb2 = 0; bool weighted = false;
+            if (MODEL == MLIRT) { ca = g; cb2 = cT; }
+            else if (fam_rt(MODEL)) {
+                if (g < p) { ca = g; cb2 = cT; }
+                else if (g < 2 * p) { ca = g - p; cb2 = cZ; }
+                else if (g == 2 * p) { ca = cT; cb2 = cT; }
+                else if (g == 2 * p + 1) { ca = cT; cb2 = cZ; }
+                else { ca = cZ; cb2 = cZ; }
+            } else if (fam_lq(MODEL)) {
+                if (g < p) { ca = g; cb2 = cT; }
+                else if (g == p) { ca = cT; cb2 = cT; }
+                else if (g < 2 * p + 1) { ca = g - p - 1; cb2 = cU; }
+                else if (g == 2 * p + 1) { ca = cT; cb2 = cU; }
+                else if (g == 2 * p + 2) { ca = cU; cb2 = cU; }
+                else if (g == 2 * p + 3) { ca = 0; cb2 = cN; }
+                else if (g == 2 * p + 4) { ca = cN; cb2 = cN; }
+                else if (g == 2 * p + 5) { ca = 0; cb2 = cZ; }
+                else if (g == 2 * p + 6) { ca = cZ; cb2 = cZ; }
+                else {
+                    // sigp_mode 1: entries of x~' W x~ (upper triangle, row-major), x~' W u, u' W u with x~ = [1 X theta], W = diag(1/nu_{t+1})
+                    const int q = p + 1, ntri = q * (q + 1) / 2;
+                    int e = g - (2 * p + 7);
+                    auto col = [&](int u) { return u < p ? u : cT; };
+                    if (e < ntri) { int u = 0; while (e >= q - u) { e -= q - u; ++u; } ca = col(u); cb2 = col(u + e); }
+                    else if (e < ntri + q) { ca = col(e - ntri); cb2 = cU; }
+                    else { ca = cU; cb2 = cU; }
+                    weighted = true;
+                }
+            } else { ca = cZ; cb2 = cZ; }      // CrossQr pass B: sum zeta^2
+            double accg = 0.0;
+            for (int li = tl; li < nrows_blk; li += 32) {
+                const real* o = sh_val + (size_t)li * NV;
+                const double va = ca == 0 ? 1.0 : (double)o[ca - 1], vb = cb2 == 0 ? 1.0 : (double)o[cb2 - 1];
+                accg += weighted ? va * vb / (double)o[cN - 1] : va * vb;
+            }
+            accg = bfly_sum(accg, 1, 32);
+            if (tl == 0) sh_gacc[g] = accg;          // wave 0's slot of the per-wave table summed by the epilogue (the other waves' stay 0)
+        }
+    }
 
     // =================================================================================================== phase 2
     // lane = item j; the waves stride over the workgroup's subjects; accumulators live in fp64 registers

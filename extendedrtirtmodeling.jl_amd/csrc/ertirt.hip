@@ -150,7 +150,7 @@ template <typename real> struct Engine : EngineBase {
     size_t pass_lds(int phase, int nWaves) const {
         const int ng = stat_sizes(phase) - nstat(phase) * J;
         size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * ((size_t)nstat(phase) * J + (size_t)ng);
-        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave) * sizeof(real);
+        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave + (size_t)rows_per_block * (Fk + 4)) * sizeof(real);
     }
 
     int init() override {
@@ -196,11 +196,16 @@ template <typename real> struct Engine : EngineBase {
         grid_blocks = cfg.grid_blocks > 0 ? cfg.grid_blocks : (int)std::min<int64_t>(need, (int64_t)cu_count * per_cu);
         if (grid_blocks < 1) grid_blocks = 1;
         // each workgroup owns a contiguous range of subjects, split evenly over its waves
-        rows_per_block = (N + grid_blocks - 1) / grid_blocks;
-        grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
-        rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
-        for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
-        if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads");
+        // (the per-subject LDS caches grow with the rows a workgroup owns: very long data sets get more workgroups than CUs)
+        for (;;) {
+            rows_per_block = (N + grid_blocks - 1) / grid_blocks;
+            grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
+            rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
+            for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
+            if (std::max(lds_pass[0], lds_pass[1]) <= 150 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
+            grid_blocks *= 2;
+        }
+        if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads or raise grid_blocks");
 
         // ---- device memory
         rows_cap = (int64_t)cfg.n_iter * cfg.n_chain;
