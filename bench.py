@@ -191,7 +191,7 @@ def main():
             algo = ALGO_BYTES[model] * cells / launches_per_sweep
             ach = algo / per_launch_s / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic_bytes(model, N, J, args), "kernel": "pass_kernel (fused row pass)",
+                               "traffic": traffic_bytes(model, N, J, args), "kernel": "pass_kernel (one launch per sweep: tiny step + fused row pass; CrossQr: one of its two row passes)",
                                "frac_of_achievable": ach / 6300.0, "achievable_peak": 6300.0, "launch_us": per_launch_s * 1e6, "event_overhead_us": tm["event_overhead_ms"] * 1e3,
                                "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"])}
         ncpu = args.cpu_sweeps

@@ -77,6 +77,7 @@ template <typename real> struct PassArgs {
     int J; int nFeat; int W; int logW; int IPL;
     int mode;             // 0 = prologue (no theta/zeta draws, no LL, no trace), 1 = full sweep pass
     int ngx;              // extra global statistics inserted before the log-likelihood slot (LatentQr sigp_mode 1: the 1/nu-weighted Gram entries)
+    int skew;             // FUSED kernels: subjects taken off wave 0's slice (it runs the structural chain of the tiny step first)
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // diagnostics only: skip everything after stage k (0 = run everything)
 };
@@ -110,6 +111,467 @@ constexpr int GROUP = 16;  // workgroups whose slab rows are summed by the last 
 constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Tiny step
+// ---------------------------------------------------------------------------------------------------------------------
+// out[e] = sum over the nb rows of `slab` (row length NS) in row order, 16 loads in flight; the same order wherever statistics are
+// reduced, so a sweep's log-likelihood does not depend on which kernel happened to reduce it
+__device__ __forceinline__ void reduce_rows(const double* slab, int nb, int NS, double* out, int tid, int nthreads)
+{
+    for (int e = tid; e < NS; e += nthreads) {
+        double t = 0.0;
+        for (int b0 = 0; b0 < nb; b0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = slab[(size_t)(b0 + u < nb ? b0 + u : b0) * NS + e];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += (b0 + u < nb) ? v[u] : 0.0;
+        }
+        out[e] = t;
+    }
+}
+
+struct TinyArgs {
+    const double* par; double* par_out;             // parameter block read / written (the same buffer unless the step runs redundantly in every workgroup)
+    const double* cst; const double* slab0; const double* slab1;
+    const Ctl* ctl; Ctl* ctl_out; Ctl* ctl_err;     // counters read / written; sticky error flag
+    double* tr_item;      // [rows][4J + NQ] : a, b, lambda, sig2t, then the small part of qr
+    double* tr_ll;        // [rows]
+    long long N; int J; int nFeat; int nb0, nb1;
+    int mode;             // 0 = draw sweep (advance ctl), 1 = final (only reduce the last pass's log-likelihood)
+    int first;            // 1 if no full pass precedes this step in the current sample! call
+    int intercept, onepl, cov2one, sigp_mode;
+    uint32_t chain; uint64_t seed; double k1, k2;
+    int nq;               // number of small qr entries recorded per sweep
+    int ngx;              // extra global statistics of slab0 (see PassArgs::ngx)
+    int dbg_stop;         // diagnostics only: return after stage k (0 = run everything)
+};
+
+__device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
+{
+    const double d1 = 1.0 / sqrt(S[0]);
+    S[0] *= d1 * d1; S[1] *= d1; S[2] *= d1;
+    const double d2 = 1.0 / sqrt(S[3]);
+    S[3] *= d2 * d2; S[1] *= d2; S[2] *= d2;
+    S[0] = 1.0; S[3] = 1.0;
+}
+
+// lower Cholesky factor of the n x n matrix V (column-major, leading dimension n) into L: one column per step, rows in parallel
+// across the lanes of ONE wave; all lanes of the wave must call it
+__device__ inline void chol_lower_wave(int n, const double* V, double* L, int lane)
+{
+    for (int jj = 0; jj < n; ++jj) {
+        double t = 0.0;
+        if (lane >= jj && lane < n) {
+            t = V[lane + jj * n];
+            for (int k = 0; k < jj; ++k) t -= L[lane + k * n] * L[jj + k * n];
+        }
+        const double d = sqrt(__shfl(t, jj, 64));
+        if (lane >= jj && lane < n) L[lane + jj * n] = (lane == jj) ? d : t / d;
+        wave_sync();
+    }
+}
+// i-th standard normal of stream (BETA, 0, 0, sweep): words 2i, 2i+1, i.e. block i/2 -- the oracle draws them consecutively
+__device__ inline double beta_normal(uint64_t seed, uint32_t chain, uint32_t sweep, int i)
+{
+    uint32_t w0, w1, w2, w3;
+    philox4x32_10(0u, 0u, sweep, ((uint32_t)SITE_BETA << 24) | ((chain & 0xFFu) << 16) | (uint32_t)(i >> 1), (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
+    const double u1 = word_to_unif<double>((i & 1) ? w2 : w0), u2 = word_to_unif<double>((i & 1) ? w3 : w1);
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+constexpr int TINY_THREADS = 1024;
+constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX + 16;   // LDS scratch doubles for the structural wave
+
+// One tiny step = tiny_items (every thread of the workgroup; no barrier inside), a workgroup barrier, tiny_struct (ONE wave; only
+// wave-level synchronisation inside).  Both work on an LDS-resident parameter block `par` (read: the previous values, written in
+// place: this sweep's).  st0 / st1: reduced statistics of the previous pass(es); part: >= J doubles of scratch; work: TINY_WORK
+// doubles; sh_x: x'x and its inverse.  STEP: 0 = the per-sweep step of single-pass models / Cross-family step 1; 1 = Cross-family
+// step 2 (lambda, sig2t).
+#define ERM_TINY_COMMON                                                                                          \
+    const int J = T.J, p = T.nFeat + 1;                                                                          \
+    const double Nd = (double)T.N;                                                                               \
+    constexpr int NSTAT0 = Stats<MODEL, 0>::NSTAT;                                                               \
+    constexpr int NSTAT1 = fam_cq(MODEL) ? Stats<CROSSQR, 1>::NSTAT : 0;                                         \
+    const double* K0 = cstp + cst_off_k0(J);                /* cstp: the item constants (global or an LDS copy) */ \
+    const double* cm = cstp + cst_off_m(J);                                                                      \
+    const double* csq = cstp + cst_off_csq(J);                                                                   \
+    const double muLam = cstp[cst_off_mu(J)], sdLam = cstp[cst_off_mu(J) + 1];                                   \
+    double* Sigp = par + par_off_sigp(J);                                                                        \
+    double* beta = par + par_off_beta(J);                                                                        \
+    const double* G0 = st0 + NSTAT0 * J;                    /* global statistics of slab0 */                     \
+    double* spd = work + TINY_WORK - 4;                     /* pre-drawn variates of the Sigma_p draw */          \
+    double* bn = work + TINY_WORK - 4 - 2 * PMAX;           /* beta_t, contiguous [2p] / [p+1] */                 \
+    double* qf = work + TINY_WORK - 12 - 2 * PMAX;          /* quadratic forms for Sigma_p (RtIrt) */             \
+    (void)Nd; (void)NSTAT1; (void)K0; (void)cm; (void)csq; (void)muLam; (void)sdLam; (void)Sigp; (void)beta; (void)G0; (void)spd; (void)bn; (void)qf;
+
+// item draws (threads 128..) and the variates of the Sigma_p draw (thread 64): neither depends on beta_t
+template <int MODEL, int STEP>
+__device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const double* st0, const double* st1, double* part, double* work, uint32_t sweep,
+                                           const double* cstp)
+{
+    ERM_TINY_COMMON
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    //   RtIrt   : c1^2 ~ chi2(N+3), n21 ~ N(0,1), c2^2 ~ chi2(N+2) (Bartlett factor of the Wishart; same stream order as the oracle)
+    //   others  : g ~ Gamma(shape) of the InverseGamma
+    if (tid == 64 && STEP == 0 && MODEL != MLIRT) {
+        Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
+        if (fam_rt(MODEL)) {
+            const double df = Nd + 3.0;
+            spd[0] = sqrt(chisq(ss, df));
+            spd[1] = normal<double>(ss);
+            spd[2] = sqrt(chisq(ss, df - 1.0));
+        } else {
+            spd[0] = gamma_mt(ss, 1e-3 + (MODEL == LATENTQR ? Nd * 3.0 / 2.0 : Nd / 2.0));
+        }
+    }
+    // =========================================================== item draws: one thread per item, in waves 2..; when the workgroup has
+    // enough threads the response-time draws (lambda, sig2t) of an item run on a second thread, concurrently with its (b, a) draws
+    const int nit = nthreads - 128;
+    const int rt_off = (nit >= 2 * J) ? J : 0;
+    for (int j = tid - 128; tid >= 128 && j < J; j += (rt_off ? 2 * J : nit)) {
+        if (STEP == 0) {
+            const double S0 = st0[0 * J + j], S1 = st0[1 * J + j], S2 = st0[2 * J + j], K1 = st0[3 * J + j];
+            double a = par[j], b = par[J + j];
+            if (fam_cq(MODEL)) {
+                // rho_t: drawSubjCorrCrossQr src/Draw.pl.jl:474-489 / drawSubjCorrCross :463-469 (uses sig2t_{t-1})
+                const double sg = par[3 * J + j];
+                const double R0 = st1[0 * J + j], R1 = st1[1 * J + j];
+                const double parV = 1.0 / (1.0 + R0 / (sg * T.k2));
+                const double parM = parV * (0.0 + R1 / (sg * T.k2));
+                Stream sr(T.seed, T.chain, SITE_RHO, 0u, (uint32_t)j, sweep);
+                par[4 * J + j] = parM + sqrt(parV) * normal<double>(sr);
+            }
+            auto draw_b = [&]() {   // drawItemDifficulty src/Draw.pl.jl:98-105
+                const double parV = 1.0 / (1.0 + a * a * S0);
+                const double parM = parV * (0.0 - (a * K0[j] - a * a * S1));
+                Stream sb(T.seed, T.chain, SITE_B, 0u, (uint32_t)j, sweep);
+                double v = parM + sqrt(parV) * normal<double>(sb);
+                b = v < -4.0 ? -4.0 : (v > 4.0 ? 4.0 : v);
+            };
+            auto draw_a = [&]() {   // drawItemDiscrimination src/Draw.pl.jl:88-93
+                const double parV = 1.0 / (1.0 + (S2 - 2.0 * b * S1 + b * b * S0));
+                const double parM = parV * (1.0 + (K1 - b * K0[j]));
+                Stream sa(T.seed, T.chain, SITE_A, 0u, (uint32_t)j, sweep);
+                a = truncnorm0(sa, parM, sqrt(parV));
+                if (T.onepl) a = 1.0;
+            };
+            if (MODEL == MLIRT) { draw_a(); draw_b(); }   // src/GibbsRtIrt.pl.jl:233-237
+            else { draw_b(); draw_a(); }                  // :301-305
+            par[j] = a; par[J + j] = b;
+        }
+    }
+    for (int j = tid - 128 - rt_off; tid >= 128 + rt_off && j < J; j += (rt_off ? 2 * J : nit)) {
+        if ((fam_rt(MODEL) || fam_lq(MODEL)) && STEP == 0) {
+            // lambda: drawItemIntensity src/Draw.pl.jl:215-220 ; sig2t: drawItemTimeResidual :257-262
+            // sum zeta, sum zeta^2 over subjects (RtIrt: (x'zeta)[0] and zz; LatentQr: tracked explicitly)
+            const double sz = fam_rt(MODEL) ? G0[p] : G0[2 * p + 5];
+            const double zz = fam_rt(MODEL) ? G0[2 * p + 2] : G0[2 * p + 6];
+            const double Gj = st0[4 * J + j];
+            const double sg_old = par[3 * J + j];
+            const double parV = 1.0 / (1.0 / (sdLam * sdLam) + Nd / sg_old);
+            const double parM = parV * (muLam / (sdLam * sdLam) + (Nd * cm[j] + sz) / sg_old);
+            Stream sl(T.seed, T.chain, SITE_LAMBDA, 0u, (uint32_t)j, sweep);
+            const double lam = truncnorm0(sl, parM, sqrt(parV));
+            const double lc = lam - cm[j];
+            const double ssq = csq[j] + 2.0 * Gj + zz - 2.0 * lc * sz + Nd * lc * lc;
+            Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
+            const double sg = invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq / 2.0);
+            par[2 * J + j] = lam; par[3 * J + j] = sg;
+            part[j] = 1.0 / sg;
+        }
+        if (fam_cq(MODEL) && STEP == 1) {
+            // lambda: drawItemIntensityCrossQr src/Draw.pl.jl:239-251 / ...Cross :225-231 ; sig2t: drawItemTimeResidualCrossQr :278-288 / ...Cross :267-273
+            const double W0 = st0[4 * J + j], W1 = st0[5 * J + j], W2 = st0[6 * J + j], V = st0[7 * J + j];
+            const double sg_old = par[3 * J + j];
+            const double parV = 1.0 / (1.0 / (sdLam * sdLam) + W0 / (sg_old * T.k2));
+            const double parM = parV * (muLam / (sdLam * sdLam) + (W1 + cm[j] * W0) / (sg_old * T.k2));
+            Stream sl(T.seed, T.chain, SITE_LAMBDA, 0u, (uint32_t)j, sweep);
+            const double lam = truncnorm0(sl, parM, sqrt(parV));
+            const double lc = lam - cm[j];
+            const double ssq = (W2 - 2.0 * lc * W1 + lc * lc * W0) / (2.0 * T.k2);
+            Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
+            const double sg = (MODEL == CROSSQR) ? invgamma(sv, 1e-3 + Nd * 3.0 / 2.0, 1e-3 + ssq + V) : invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq);
+            par[2 * J + j] = lam; par[3 * J + j] = sg;
+            part[j] = 1.0 / sg;
+        }
+        if (MODEL == MLIRT || (fam_cq(MODEL) && STEP == 0)) part[j] = 1.0 / par[3 * J + j];   // sig2t not drawn in this step
+    }
+}
+
+// structural draws by ONE wave (lane = its lane index): beta_t (lanes cooperate through LDS), sum_j 1/sig2t_j, Sigma_p_t | beta_t.
+// PART 0: only the leading part of the beta chain, which needs neither the item draws nor Sigma_p's variates (so it can run while
+// other waves draw the items); PART 1: the rest; PART 2: everything.
+template <int MODEL, int STEP, int PART>
+__device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, const double* st0, const double* st1, double* part, double* work,
+                                            const double* sh_x, uint32_t sweep, int lane)
+{
+    const double* cstp = T.cst;
+    ERM_TINY_COMMON
+    const double* XtX = sh_x;                               // p x p, column-major with leading dimension PMAX
+    const double* Xinv = sh_x + PMAX * PMAX;                // (x'x)^-1, same layout
+    (void)XtX; (void)Xinv;
+    if (STEP == 0) {
+        if (MODEL == MLIRT) {
+            if (PART != 0)
+            // getSubjCoefficientsMlIrt src/Draw.pl.jl:351-357 : beta = (x'x) \ x'theta ; beta[1] = 0 unless intercept
+            if (lane < p) {
+                double t = 0.0;
+                for (int v = 0; v < p; ++v) t += Xinv[lane + v * PMAX] * G0[v];
+                beta[lane] = (lane == 0 && !T.intercept) ? 0.0 : t;
+            }
+        } else if (MODEL == NULLM) {
+            // src/GibbsRtIrt.pl.jl:380: Para.beta = zeros(nFeat+1, 2) every sweep
+            if (PART != 0 && lane < 2 * p) { bn[lane] = 0.0; beta[(lane / p) * PMAX + (lane % p)] = 0.0; }
+            if (PART != 0 && lane < 8) qf[lane] = 0.0;
+        } else if (MODEL == RTIRT) {
+            // drawSubjCoefficients src/Draw.pl.jl:380-393.  Posterior precision = 11' + kron(inv(Sigp), x'x) (the reference's
+            // `1/sigma^2 .+ M` adds 1 to EVERY element), so by Sherman-Morrison
+            //   parV = Minv - v v'/(1 + 1'v),  Minv = kron(Sigp, (x'x)^-1),  v = Minv 1.
+            const int n = 2 * p;
+            double* V = work, *L = V + n * n, *tv = L + n * n, *vv = tv + n, *rs = vv + n, *pmv = rs + n;
+            const double* xt = G0, *xz = G0 + p;
+            if (PART != 1) {
+            const double s00 = Sigp[0], s10 = Sigp[1], s01 = Sigp[2], s11 = Sigp[3];
+            const double sdet = s00 * s11 - s10 * s01;
+            const double iO[4] = { s11 / sdet, -s10 / sdet, -s01 / sdet, s00 / sdet };
+            if (lane < p) { double t = 0.0; for (int w = 0; w < p; ++w) t += Xinv[lane + w * PMAX]; rs[lane] = t; }
+            wave_sync();
+            if (lane < n) {
+                const int a_ = lane / p, u = lane % p;
+                vv[lane] = (Sigp[a_] + Sigp[a_ + 2]) * rs[u];
+                tv[lane] = 0.0 + xt[u] * iO[a_] + xz[u] * iO[a_ + 2];      // vec(x'eta * inv(Sigp)')
+            }
+            wave_sync();
+            double cden = 1.0;
+            for (int i = 0; i < n; ++i) cden += vv[i];
+            for (int e = lane; e < n * n; e += 64) {
+                int i = e % n, jj = e / n;
+                if (i > jj) { const int t_ = i; i = jj; jj = t_; }              // Symmetric(parV): upper triangle
+                const int a_ = i / p, u = i % p, b_ = jj / p, w = jj % p;
+                V[e] = Sigp[a_ + 2 * b_] * Xinv[u + w * PMAX] - vv[i] * vv[jj] / cden;
+            }
+            wave_sync();
+            double pm = 0.0;
+            if (lane < n) for (int jj = 0; jj < n; ++jj) pm += V[lane + jj * n] * tv[jj];
+            chol_lower_wave(n, V, L, lane);
+            if (lane < n) pmv[lane] = pm;
+            }   // ---- part A ends (everything above depends only on the previous pass's statistics and Sigma_p_{t-1})
+            if (PART != 0) {
+            const double pm = lane < n ? pmv[lane] : 0.0;
+            const double zi = lane < n ? beta_normal(T.seed, T.chain, sweep, lane) : 0.0;     // z_i drawn by lane i
+            double t = pm;
+            for (int jj = 0; jj < n; ++jj) {
+                const double zj = __shfl(zi, jj, 64);
+                if (lane < n && jj <= lane) t += L[lane + jj * n] * zj;
+            }
+            if (lane < n) {
+                if (!T.intercept && (lane == 0 || lane == p)) t = 0.0;          // src/GibbsRtIrt.pl.jl:293-295
+                bn[lane] = t;
+                beta[(lane / p) * PMAX + (lane % p)] = t;
+            }
+            wave_sync();
+            // quadratic forms needed by Sigma_p: qf[a + 2b] = beta_a' x'x beta_b, qf[4 + a + 2b] = beta_a' x'eta_b; lane f computes form f
+            if (lane < 8) {
+                const int a_ = lane & 1, b_ = (lane >> 1) & 1;
+                double v = 0.0;
+                if (lane < 4) { for (int u = 0; u < p; ++u) for (int w = 0; w < p; ++w) v += bn[a_ * p + u] * XtX[u + w * PMAX] * bn[b_ * p + w]; }
+                else { const double* xe = b_ == 0 ? G0 : G0 + p; for (int u = 0; u < p; ++u) v += bn[a_ * p + u] * xe[u]; }
+                qf[lane] = v;
+            }
+            }   // PART != 0
+        } else if (MODEL == LATENT) {
+            // drawSubjCoefficientsLatent src/Draw.pl.jl:399-416, x = [1 X theta] (q = p + 1 columns):
+            //   parV = inv(11' + x'x / Sigp22)  (`1/sb0^2 .+ M` adds 1 to EVERY element), parM = parV x'zeta / Sigp22,
+            //   beta = parM + chol(Symmetric(parV)).L z
+            const int q = p + 1;
+            double* Mx = work, *L = Mx + q * q, *V = L + q * q, *tv = V + q * q;
+            const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1; const double tz = G0[2 * p + 1];
+            const double iO = 1.0 / Sigp[3];
+            if (PART != 1) {
+            for (int e = lane; e < q * q; e += 64) {
+                const int i = e % q, jj = e / q;
+                const double a_ = (i < p && jj < p) ? XtX[i + jj * PMAX] : ((i == p && jj == p) ? tt : xt[i < jj ? i : jj]);
+                Mx[e] = 1.0 + iO * a_;
+            }
+            if (lane < q) tv[lane] = 0.0 + (lane < p ? xz[lane] : tz) * iO;
+            wave_sync();
+            chol_lower_wave(q, Mx, L, lane);                     // precision = L L'
+            if (lane < q) {                                      // lane k: column k of the inverse (forward, then backward substitution)
+                const int k = lane;
+                for (int i = 0; i < q; ++i) {
+                    double t = (i == k) ? 1.0 : 0.0;
+                    for (int m = 0; m < i; ++m) t -= L[i + m * q] * V[m + k * q];
+                    V[i + k * q] = t / L[i + i * q];
+                }
+                for (int i = q - 1; i >= 0; --i) {
+                    double t = V[i + k * q];
+                    for (int m = i + 1; m < q; ++m) t -= L[m + i * q] * V[m + k * q];
+                    V[i + k * q] = t / L[i + i * q];
+                }
+            }
+            wave_sync();
+            }   // ---- part A ends
+            if (PART != 0) {
+            for (int e = lane; e < q * q; e += 64) {             // Symmetric(parV): upper triangle
+                const int i = e % q, jj = e / q;
+                Mx[e] = V[(i < jj ? i : jj) + (i < jj ? jj : i) * q];
+            }
+            wave_sync();
+            double pm = 0.0;
+            if (lane < q) for (int jj = 0; jj < q; ++jj) pm += Mx[lane + jj * q] * tv[jj];
+            chol_lower_wave(q, Mx, L, lane);
+            const double zi = lane < q ? beta_normal(T.seed, T.chain, sweep, lane) : 0.0;
+            double t = pm;
+            for (int jj = 0; jj < q; ++jj) {
+                const double zj = __shfl(zi, jj, 64);
+                if (lane < q && jj <= lane) t += L[lane + jj * q] * zj;
+            }
+            if (lane < q) {
+                if (!T.intercept && lane == 0) t = 0.0;          // src/GibbsRtIrtLatent.pl.jl:184-186
+                bn[lane] = t; beta[lane] = t;
+            }
+            }   // PART != 0
+        } else if (MODEL == LATENTQR) {
+            // getSubjCoefficientsLatentQr src/Draw.pl.jl:446-458 : beta = (x'x)^-1 x'(zeta - k1 nu), x = [1 X theta];
+            // block inverse with the constant (X~'X~)^-1 and the Schur complement of the theta column.
+            if (PART != 0 && lane == 0) {
+                const int q = p + 1;
+                const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
+                const double tu = G0[2 * p + 1];
+                double* h = work, *g = h + PMAX;
+                double hx = 0.0, hu = 0.0;
+                for (int u = 0; u < p; ++u) {
+                    double t1 = 0.0, t2 = 0.0;
+                    for (int v = 0; v < p; ++v) { t1 += Xinv[u + v * PMAX] * xt[v]; t2 += Xinv[u + v * PMAX] * xu[v]; }
+                    h[u] = t1; g[u] = t2;
+                }
+                for (int u = 0; u < p; ++u) { hx += xt[u] * h[u]; hu += h[u] * xu[u]; }
+                const double b2 = (tu - hu) / (tt - hx);
+                for (int u = 0; u < p; ++u) bn[u] = g[u] - h[u] * b2;
+                bn[p] = b2;
+                if (!T.intercept) bn[0] = 0.0;                                   // src/GibbsRtIrtLatent.pl.jl:288-290
+                for (int u = 0; u < q; ++u) beta[u] = bn[u];
+            }
+        }
+    }
+
+    wave_sync();
+    if (PART == 0) return;
+    // derived scalar for the row pass: sum_j 1/sig2t_j (part[j] = 1/sig2t_j; fixed order: lane l sums j = l, l+64, ..., then a butterfly)
+    {
+        double t = 0.0;
+        for (int jj = lane; jj < J; jj += 64) t += part[jj];
+        t = bfly_sum(t, 1, 64);
+        if (lane == 0) par[par_off_derived(J)] = t;
+    }
+    // =========================================================== Sigma_p_t | beta_t (thread 0; its random numbers were pre-drawn above)
+    if (lane == 0 && STEP == 0 && MODEL != MLIRT) {
+        double S[4] = { 1.0, 0.0, 0.0, 1.0 };
+        if (fam_rt(MODEL)) {
+            // drawSubjCovariance src/Draw.pl.jl:499-515 (Null: drawSubjCovarianceNull :522-535, the same draw with beta = 0) : InverseWishart(N+3, e'e + I), e'e from sufficient statistics
+            // (the quadratic forms beta_a' x'x beta_b and beta_a' x'eta_b were reduced by wave 0 just above: qf[0..7])
+            const double tt = G0[2 * p], tz = G0[2 * p + 1], zz = G0[2 * p + 2];
+            const double* bAb = qf; const double* bx = qf + 4;
+            const double ee00 = tt - 2.0 * bx[0] + bAb[0];
+            const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
+            const double ee11 = zz - 2.0 * bx[3] + bAb[3];
+            const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
+            const double pdet = Psi[0] * Psi[3] - Psi[1] * Psi[2];
+            const double Pi[4] = { Psi[3] / pdet, -Psi[1] / pdet, -Psi[2] / pdet, Psi[0] / pdet };
+            const double l00 = sqrt(Pi[0]), l10 = Pi[1] / l00, l11 = sqrt(Pi[3] - l10 * l10);
+            const double c1 = spd[0], n21 = spd[1], c2 = spd[2];
+            const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
+            const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
+            const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
+            S[0] = Wm[3] / det; S[1] = -Wm[1] / det; S[2] = -Wm[2] / det; S[3] = Wm[0] / det;
+        } else if (MODEL == LATENT) {
+            // drawSubjCovarianceLatent src/Draw.pl.jl:563-579 : InverseGamma(da + N/2, db + sum((zeta - x beta)^2)/2), x = [1 X theta]
+            const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1;
+            const double tz = G0[2 * p + 1], zz = G0[2 * p + 2];
+            double sr2 = zz;
+            for (int u = 0; u < p; ++u) sr2 -= 2.0 * bn[u] * xz[u];
+            sr2 -= 2.0 * bn[p] * tz;
+            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
+            for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
+            sr2 += bn[p] * bn[p] * tt;
+            S[3] = (1e-3 + sr2 / 2.0) / spd[0];
+        } else if (MODEL == LATENTQR) {
+            // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
+            const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
+            const double tu = G0[2 * p + 1], uu = G0[2 * p + 2], snu = G0[2 * p + 3], snu2 = G0[2 * p + 4];
+            double sr2 = uu;
+            for (int u = 0; u < p; ++u) sr2 -= 2.0 * bn[u] * xu[u];
+            sr2 -= 2.0 * bn[p] * tu;
+            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
+            for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
+            sr2 += bn[p] * bn[p] * tt;
+            const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
+            double quirk = sr2 * sw / sw2;
+            if (T.sigp_mode == 1) {
+                // the evidently intended sum_i r_i^2 / (2 k2 nu_i), r = u - x~ beta, from the 1/nu-weighted Gram statistics
+                const int q = p + 1, ntri = q * (q + 1) / 2;
+                const double* Wg = G0 + 2 * p + 7;
+                double sw_r2 = Wg[ntri + q];
+                for (int u = 0; u < q; ++u) sw_r2 -= 2.0 * bn[u] * Wg[ntri + u];
+                int e = 0;
+                for (int u = 0; u < q; ++u) for (int v = u; v < q; ++v, ++e) sw_r2 += (u == v ? 1.0 : 2.0) * bn[u] * Wg[e] * bn[v];
+                quirk = sw_r2 / (2.0 * T.k2);
+            }
+            const double parB = 1e-3 + quirk + snu;
+            S[3] = parB / spd[0];
+        } else {
+            // drawSubjCovarianceCross src/Draw.pl.jl:542-557
+            const double zz = st1[NSTAT1 * J + 0];
+            S[3] = (1e-3 + zz / 2.0) / spd[0];
+        }
+        if (T.cov2one) d_cov2one(S);
+        for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
+    }
+    wave_sync();
+}
+
+// the whole step in a single workgroup
+template <int MODEL, int STEP>
+__device__ __forceinline__ void tiny_draws(const TinyArgs& T, double* par, const double* st0, const double* st1, double* part, double* work,
+                                           const double* sh_x, uint32_t sweep)
+{
+    tiny_items<MODEL, STEP>(T, par, st0, st1, part, work, sweep, T.cst);
+    __syncthreads();
+    if (threadIdx.x < 64) tiny_struct<MODEL, STEP, 2>(T, par, st0, st1, part, work, sh_x, sweep, (int)threadIdx.x);
+    __syncthreads();
+}
+
+// Bookkeeping of one tiny step by ONE workgroup: item-level trace row, finite check, the updated parameter block and the sweep / row
+// counters go to global memory (par_out / ctl_out may alias the inputs when a single workgroup runs the step).
+template <int MODEL, int STEP>
+__device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* par, uint32_t sweep, uint32_t row, int tid, int nthreads)
+{
+    const int J = T.J, p = T.nFeat + 1;
+    const double* Sigp = par + par_off_sigp(J);
+    const double* beta = par + par_off_beta(J);
+    const bool last_step = (MODEL != CROSSQR) || STEP == 1;
+    if (last_step && T.tr_item) {
+        const int wrow = 4 * J + T.nq;
+        double* tr = T.tr_item + (size_t)row * wrow;
+        for (int e = tid; e < 4 * J; e += nthreads) tr[e] = par[e];
+        for (int k = tid; k < T.nq; k += nthreads) {
+            double v;
+            if (MODEL == MLIRT) v = beta[k];
+            else if (fam_rt(MODEL)) { const int nb = 2 * p; v = k < nb ? (k < p ? beta[k] : beta[PMAX + k - p]) : Sigp[k - nb]; }
+            else if (fam_cq(MODEL)) v = k < J ? par[4 * J + k] : Sigp[k - J];
+            else { const int nb = p + 1; v = k < nb ? beta[k] : Sigp[k - nb]; }
+            tr[4 * J + k] = v;
+        }
+    }
+    for (int e = tid; e < par_size(J); e += nthreads) {
+        if (!(fabs(par[e]) < 1e300)) atomicCAS(&T.ctl_err->err, 0u, 1u + (uint32_t)e);   // a non-finite entry of the parameter block
+        T.par_out[e] = par[e];
+    }
+    if (tid == 0 && STEP == 0) { T.ctl_out->sweep = sweep; T.ctl_out->row = row; T.ctl_out->burn_rows = T.ctl->burn_rows; }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Row pass.  blockDim.x = 64 * nWaves; workgroup b owns a contiguous range of subjects.
 //   phase 1 (lane (r, s) of a wave: subject r of the wave's group, items s, s+W, ...):
 //       row sums over omega_t / Y / logT, theta_t and zeta_t draws, per-subject outputs and global statistics, then the
@@ -119,8 +581,12 @@ constexpr int KB = 4;     // items per lane whose loads are in flight together i
 //       statistics, accumulated in fp64 REGISTERS with no cross-lane traffic; CrossQr's per-cell nu_{t+1} draw lives here.
 //   epilogue: fixed-order sum of the waves' accumulators -> this workgroup's slab row.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MODEL, typename real, int PHASE>
-__global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(PassArgs<real> A)
+// FUSED (single-pass models): the kernel first runs this sweep's tiny step itself -- every workgroup redundantly, from the previous
+// launch's group-reduced statistics (T.slab0) and parameter block (T.par), bit-identically; workgroup 0 publishes the results
+// (T.par_out, T.ctl_out, traces).  Inputs and outputs are distinct (double-buffered) allocations, so a workgroup that starts late
+// never sees a half-updated block.  That removes one kernel boundary and the tiny kernel's cold start from every sweep.
+template <int MODEL, typename real, int PHASE, bool FUSED>
+__global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(PassArgs<real> A, TinyArgs T)
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
@@ -146,45 +612,96 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     const real* __restrict__ gC = A.C;
     const real* __restrict__ gX = A.X;
 
-    const uint32_t sweep = A.ctl->sweep;
-    const uint32_t trow = A.ctl->row;
+    uint32_t sweep = A.ctl->sweep, trow = A.ctl->row;
+    const double* parsrc = A.par;
+    // FUSED only: LDS scratch of the tiny step, appended to the pass layout
+    const int NS0 = NSTAT * J + NG;
+    double* st0 = reinterpret_cast<double*>(sh_val + (((size_t)A.rows_per_block * NV + 1) & ~(size_t)1));   // 8-byte aligned
+    double* part = st0 + NS0;
+    double* work = part + NS0;
+    double* sh_x = work + TINY_WORK;
+    double* lp = sh_x + 2 * PMAX * PMAX;
+    double* lcst = lp + par_size(J);                            // K0, column means, csq, muLam, sdLam (3J + 2)
+    const bool writer = blockIdx.x == 0;
+    if constexpr (FUSED) {
+        // ------------------------------------------------------------------------------------------------ this sweep's tiny step
+        const int tid = threadIdx.x, nthr = blockDim.x;
+        for (int e = tid; e < 2 * PMAX * PMAX; e += nthr) sh_x[e] = T.cst[cst_off_xtx(J) + e];
+        for (int e = tid; e < par_size(J); e += nthr) lp[e] = T.par[e];
+        for (int e = tid; e < 3 * J + 2; e += nthr) lcst[e] = T.cst[e];
+        reduce_rows(T.slab0, T.nb0, NS0, st0, tid, nthr);
+        __syncthreads();
+        if (A.dbg_stop == 30) return;
+        const uint32_t prev_row = T.ctl->row;
+        sweep = T.ctl->sweep + 1u;
+        trow = T.first ? prev_row : prev_row + 1u;
+        if (writer && tid == 0 && !T.first && T.tr_ll) T.tr_ll[prev_row] = st0[NS0 - 1];    // log-likelihood of the sweep the last pass completed
+        // item draws now; the structural chain (beta_t -> Sigma_p_t, ~7 us of dependent fp64 work on one wave) runs on wave 0 AFTER the
+        // staging barrier below, concurrently with the other waves' row sums, which do not need it (see `sh_ready`)
+        tiny_items<MODEL, 0>(T, lp, st0, nullptr, part, work, sweep, lcst);
+        if (wave == 0) tiny_struct<MODEL, 0, 0>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);   // threads < 128 draw no items
+        __syncthreads();
+        if (A.dbg_stop == 31) return;
+        parsrc = lp;
+    }
     const bool post_burn = trow >= A.ctl->burn_rows;
+    int* sh_ready = reinterpret_cast<int*>(sh_struct + 5);      // FUSED: set by wave 0 once sh_struct holds Sigma_p_t, beta_t, sum 1/sig2t
 
     // ---- stage item parameters and structural scalars
     for (int j = threadIdx.x; j < J; j += blockDim.x) {
-        const double a = A.par[j], b = A.par[J + j], lam = A.par[2 * J + j], sg = A.par[3 * J + j], rho = A.par[4 * J + j];
+        const double a = parsrc[j], b = parsrc[J + j], lam = parsrc[2 * J + j], sg = parsrc[3 * J + j], rho = parsrc[4 * J + j];
         sh_a[j] = (real)a; sh_b[j] = (real)b; sh_a2[j] = (real)(a * a); sh_a2b[j] = (real)(a * a * b);
-        sh_lamc[j] = (real)(lam - A.cst[cst_off_m(J) + j]); sh_isig[j] = (real)(1.0 / sg); sh_lsig[j] = (real)log(sg); sh_rho[j] = (real)rho;
+        sh_lamc[j] = (real)(lam - (FUSED ? lcst[cst_off_m(J) + j] : A.cst[cst_off_m(J) + j])); sh_isig[j] = (real)(1.0 / sg); sh_lsig[j] = (real)log(sg); sh_rho[j] = (real)rho;
     }
-    if (threadIdx.x < 8 + 2 * PMAX) {
+    if (FUSED && threadIdx.x == 0) *sh_ready = 0;
+    if (!FUSED && threadIdx.x < 8 + 2 * PMAX) {
         double v = 0.0;
-        if (threadIdx.x < 4) v = A.par[par_off_sigp(J) + threadIdx.x];
-        else if (threadIdx.x >= 8) v = A.par[par_off_beta(J) + threadIdx.x - 8];
-        else if (threadIdx.x == 4) v = A.par[par_off_derived(J)];                // sum_j 1/sig2t_j
+        if (threadIdx.x < 4) v = parsrc[par_off_sigp(J) + threadIdx.x];
+        else if (threadIdx.x >= 8) v = parsrc[par_off_beta(J) + threadIdx.x - 8];
+        else if (threadIdx.x == 4) v = parsrc[par_off_derived(J)];                // sum_j 1/sig2t_j
         sh_struct[threadIdx.x] = v;
     }
     for (int e = threadIdx.x; e < nWaves * NG; e += blockDim.x) sh_gacc[e] = 0.0;
     __syncthreads();
 
-    const real sig11 = (MODEL == MLIRT) ? real(1) : (real)sh_struct[0];
-    const real sig22 = (real)sh_struct[3];
-    const real sum_isig = (real)sh_struct[4];
-    const double* beta = sh_struct + 8;
+    if (A.dbg_stop == 32) return;
+    if constexpr (FUSED) {
+        if (wave == 0) {
+            // structural chain of this sweep's tiny step on wave 0 while waves 1.. stream their row sums; its results (Sigma_p_t, beta_t,
+            // sum 1/sig2t) are first needed by phase 1 (ii), whose entry waits on sh_ready.  Wave 0 owns fewer subjects (A.skew) to make up.
+            tiny_struct<MODEL, 0, 1>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);
+            if (lane < 8 + 2 * PMAX) {
+                double v = 0.0;
+                if (lane < 4) v = lp[par_off_sigp(J) + lane];
+                else if (lane >= 8) v = lp[par_off_beta(J) + lane - 8];
+                else if (lane == 4) v = lp[par_off_derived(J)];
+                if (lane != 5) sh_struct[lane] = v;                 // slot 5 is sh_ready
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(sh_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (writer) tiny_publish<MODEL, 0>(T, lp, sweep, trow, lane, 64);
+        }
+    }
     const real k1 = (real)A.k1, k2 = (real)A.k2;
-    // bivariate-normal log-density constants of Sigma_p (src/GibbsRtIrt.pl.jl:268-269)
-    const double sp_det = sh_struct[0] * sh_struct[3] - sh_struct[1] * sh_struct[2];
-    const double sp_c0 = -LOG_2PI - 0.5 * log(sp_det);
-    const double sp_q00 = sh_struct[3] / sp_det, sp_q01 = -(sh_struct[1] + sh_struct[2]) / sp_det, sp_q11 = sh_struct[0] / sp_det;
     double* acc = sh_acc + (size_t)wave * NSTAT * J;
     double ll = 0.0;
 
     const long long row0 = (long long)blockIdx.x * A.rows_per_block;
     const long long row1 = (row0 + A.rows_per_block < A.N) ? row0 + A.rows_per_block : A.N;
-    // wave w owns a contiguous, balanced slice [ra, rb) of the workgroup's subjects
+    // wave w owns a contiguous slice [ra, rb) of the workgroup's subjects: balanced, except that a FUSED kernel's wave 0 (busy with the
+    // structural chain first) gets A.skew subjects fewer
     const int nrows_blk = (int)(row1 - row0);
-    const int rbase = nrows_blk / nWaves, rrem = nrows_blk % nWaves;
-    const long long ra = row0 + (long long)wave * rbase + (wave < rrem ? wave : rrem);
-    const long long rb = ra + rbase + (wave < rrem ? 1 : 0);
+    long long ra, rb;
+    if (FUSED && nWaves > 1) {
+        int r0 = nrows_blk / nWaves - A.skew; if (r0 < 0) r0 = 0;
+        const int rest = nrows_blk - r0, rbase = rest / (nWaves - 1), rrem = rest % (nWaves - 1);
+        if (wave == 0) { ra = row0; rb = row0 + r0; }
+        else { const int w = wave - 1; ra = row0 + r0 + (long long)w * rbase + (w < rrem ? w : rrem); rb = ra + rbase + (w < rrem ? 1 : 0); }
+    } else {
+        const int rbase = nrows_blk / nWaves, rrem = nrows_blk % nWaves;
+        ra = row0 + (long long)wave * rbase + (wave < rrem ? wave : rrem);
+        rb = ra + rbase + (wave < rrem ? 1 : 0);
+    }
     if (A.dbg_stop == 1) return;
 
     // =================================================================================================== phase 1 (i)
@@ -236,6 +753,19 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
 
     // =================================================================================================== phase 1 (ii)
     // one lane per subject: theta_t / zeta_t draws, per-subject outputs, structural log-likelihood, LatentQr's nu_{t+1}
+    if constexpr (FUSED) {
+        // wave 0 finished the structural chain long before any wave gets here (it takes less time than the row sums); the wait is a guard
+        while (__hip_atomic_load(sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    const real sig11 = (MODEL == MLIRT) ? real(1) : (real)sh_struct[0];
+    const real sig22 = (real)sh_struct[3];
+    const real sum_isig = (real)sh_struct[4];
+    const double* beta = sh_struct + 8;
+    // bivariate-normal log-density constants of Sigma_p (src/GibbsRtIrt.pl.jl:268-269)
+    const double sp_det = sh_struct[0] * sh_struct[3] - sh_struct[1] * sh_struct[2];
+    const double sp_c0 = -LOG_2PI - 0.5 * log(sp_det);
+    const double sp_q00 = sh_struct[3] / sp_det, sp_q01 = -(sh_struct[1] + sh_struct[2]) / sp_det, sp_q11 = sh_struct[0] / sp_det;
     for (long long ib = ra; ib < rb; ib += 64) {
         const bool rok = ib + lane < rb;
         const long long i = rok ? ib + lane : ra;          // clamped: loads are unconditional, stores masked
@@ -568,7 +1098,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     const int gcount = ((int)gridDim.x - gfirst < GROUP) ? (int)gridDim.x - gfirst : GROUP;
     if (threadIdx.x == 0) {
         const unsigned int ticket = __hip_atomic_fetch_add(A.gcnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (ticket == (unsigned int)(gcount - 1)) ? 1 : 0;
+        const int last = (ticket % (unsigned int)gcount == (unsigned int)(gcount - 1)) ? 1 : 0;   // counters only ever grow (zeroed by the host per erm_run)
         if (last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -590,66 +1120,12 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Tiny step
-// ---------------------------------------------------------------------------------------------------------------------
-struct TinyArgs {
-    double* par; const double* cst; const double* slab0; const double* slab1; Ctl* ctl;
-    unsigned int* gcnt0; unsigned int* gcnt1;       // arrival counters of the pass kernels, re-armed here
-    double* tr_item;      // [rows][4J + NQ] : a, b, lambda, sig2t, then the small part of qr
-    double* tr_ll;        // [rows]
-    long long N; int J; int nFeat; int nb0, nb1;
-    int mode;             // 0 = draw sweep (advance ctl), 1 = final (only reduce the last pass's log-likelihood)
-    int first;            // 1 if no full pass precedes this step in the current sample! call
-    int intercept, onepl, cov2one, sigp_mode;
-    uint32_t chain; uint64_t seed; double k1, k2;
-    int nq;               // number of small qr entries recorded per sweep
-    int ngx;              // extra global statistics of slab0 (see PassArgs::ngx)
-    int dbg_stop;         // diagnostics only: return after stage k (0 = run everything)
-};
+constexpr int tiny_lds_doubles(int NS0, int NS1, int J) { return NS0 + NS1 + 4 * (NS0 > NS1 ? NS0 : NS1) + TINY_WORK + 2 * PMAX * PMAX + par_size(J); }
 
-__device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
-{
-    const double d1 = 1.0 / sqrt(S[0]);
-    S[0] *= d1 * d1; S[1] *= d1; S[2] *= d1;
-    const double d2 = 1.0 / sqrt(S[3]);
-    S[3] *= d2 * d2; S[1] *= d2; S[2] *= d2;
-    S[0] = 1.0; S[3] = 1.0;
-}
-
-// lower Cholesky factor of the n x n matrix V (column-major, leading dimension n) into L: one column per step, rows in parallel
-// across the lanes of ONE wave; all lanes of the wave must call it
-__device__ inline void chol_lower_wave(int n, const double* V, double* L, int lane)
-{
-    for (int jj = 0; jj < n; ++jj) {
-        double t = 0.0;
-        if (lane >= jj && lane < n) {
-            t = V[lane + jj * n];
-            for (int k = 0; k < jj; ++k) t -= L[lane + k * n] * L[jj + k * n];
-        }
-        const double d = sqrt(__shfl(t, jj, 64));
-        if (lane >= jj && lane < n) L[lane + jj * n] = (lane == jj) ? d : t / d;
-        wave_sync();
-    }
-}
-// i-th standard normal of stream (BETA, 0, 0, sweep): words 2i, 2i+1, i.e. block i/2 -- the oracle draws them consecutively
-__device__ inline double beta_normal(uint64_t seed, uint32_t chain, uint32_t sweep, int i)
-{
-    uint32_t w0, w1, w2, w3;
-    philox4x32_10(0u, 0u, sweep, ((uint32_t)SITE_BETA << 24) | ((chain & 0xFFu) << 16) | (uint32_t)(i >> 1), (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
-    const double u1 = word_to_unif<double>((i & 1) ? w2 : w0), u2 = word_to_unif<double>((i & 1) ? w3 : w1);
-    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
-}
-
-constexpr int TINY_THREADS = 1024;
-constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX + 16;   // LDS scratch doubles for the structural wave
-
-// STEP: 0 = the per-sweep step of single-pass models / CrossQr step 1; 1 = CrossQr step 2 (lambda, sig2t)
 template <int MODEL, int STEP>
 __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
 {
     const int J = T.J, p = T.nFeat + 1;
-    const double Nd = (double)T.N;
     constexpr int NSTAT0 = Stats<MODEL, 0>::NSTAT;
     const int NG0 = Stats<MODEL, 0>::ng(p) + T.ngx;
     const int NS0 = NSTAT0 * J + NG0;
@@ -663,34 +1139,14 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     double* part = st1 + NS1;                               // 4 * max(NS0, NS1) partial sums
     double* work = part + 4 * (NS0 > NS1 ? NS0 : NS1);      // TINY_WORK scratch
     double* sh_x = work + TINY_WORK;                        // x'x and its inverse (2 * PMAX * PMAX), staged once
+    double* lp = sh_x + 2 * PMAX * PMAX;                    // the parameter block, updated in place and written back at the end
     const int tid = threadIdx.x;
     if (tid < 2 * PMAX * PMAX) sh_x[tid] = T.cst[cst_off_xtx(T.J) + tid];
+    for (int e = tid; e < par_size(J); e += TINY_THREADS) lp[e] = T.par[e];
 
-    // ---- fixed-order slab reduction: 4 chains per statistic, each with 8 independent partial sums (loads in flight)
-    auto reduce = [&](const double* slab, int nb, int NS, double* out) {
-        const int part_id = tid >> 8, e0 = tid & 255;
-        for (int e = e0; e < NS; e += 256) {
-            double t[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = 0.0;
-            int b = part_id;
-            for (; b + 60 < nb; b += 64) {
-#pragma unroll
-                for (int u = 0; u < 16; ++u) t[u] += slab[(size_t)(b + 4 * u) * NS + e];
-            }
-            for (; b < nb; b += 4) t[0] += slab[(size_t)b * NS + e];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] += t[u + 8];
-            part[part_id * NS + e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-        }
-        __syncthreads();
-        for (int e = tid; e < NS; e += TINY_THREADS) out[e] = (part[e] + part[NS + e]) + (part[2 * NS + e] + part[3 * NS + e]);
-        __syncthreads();
-    };
-    if (tid < T.nb0) T.gcnt0[tid] = 0u;                     // re-arm the group counters for the next pass (kernel boundary orders this)
-    if (fam_cq(MODEL) && tid < T.nb1) T.gcnt1[tid] = 0u;
-    reduce(T.slab0, T.nb0, NS0, st0);
-    if (fam_cq(MODEL) && STEP == 0) reduce(T.slab1, T.nb1, NS1, st1);
+    reduce_rows(T.slab0, T.nb0, NS0, st0, tid, TINY_THREADS);
+    if (fam_cq(MODEL) && STEP == 0) reduce_rows(T.slab1, T.nb1, NS1, st1, tid, TINY_THREADS);
+    __syncthreads();
 
     const uint32_t prev_row = T.ctl->row;
     const uint32_t sweep = T.ctl->sweep + ((T.mode == 0 && STEP == 0) ? 1u : 0u);   // the sweep being drawn
@@ -705,329 +1161,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     if (T.mode == 1) return;
     if (T.dbg_stop == 1) return;
 
-    const double* K0 = T.cst + cst_off_k0(J);
-    const double* cm = T.cst + cst_off_m(J);
-    const double* csq = T.cst + cst_off_csq(J);
-    const double muLam = T.cst[cst_off_mu(J)], sdLam = T.cst[cst_off_mu(J) + 1];
-    const double* XtX = sh_x;                               // p x p, column-major with leading dimension PMAX
-    const double* Xinv = sh_x + PMAX * PMAX;                // (x'x)^-1, same layout
-    double* par = T.par;
-    double* Sigp = par + par_off_sigp(J);
-    double* beta = par + par_off_beta(J);
-    const double* G0 = st0 + NSTAT0 * J;                    // global statistics of slab0
-
-    // =========================================================== structural draws
-    // wave 1, lane 0: the random numbers of the Sigma_p draw do not depend on beta_t, so they are drawn concurrently with it:
-    //   RtIrt   : c1^2 ~ chi2(N+3), n21 ~ N(0,1), c2^2 ~ chi2(N+2) (Bartlett factor of the Wishart; same stream order as the oracle)
-    //   others  : g ~ Gamma(shape) of the InverseGamma
-    double* spd = work + TINY_WORK - 4;
-    if (tid == 64 && STEP == 0 && MODEL != MLIRT) {
-        Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
-        if (fam_rt(MODEL)) {
-            const double df = Nd + 3.0;
-            spd[0] = sqrt(chisq(ss, df));
-            spd[1] = normal<double>(ss);
-            spd[2] = sqrt(chisq(ss, df - 1.0));
-        } else {
-            spd[0] = gamma_mt(ss, 1e-3 + (MODEL == LATENTQR ? Nd * 3.0 / 2.0 : Nd / 2.0));
-        }
-    }
-    // wave 0: beta_t (lanes cooperate through LDS)
-    double* bn = work + TINY_WORK - 4 - 2 * PMAX;           // beta_t, contiguous [2p] / [p+1]
-    double* qf = work + TINY_WORK - 12 - 2 * PMAX;          // quadratic forms for Sigma_p (RtIrt)
-    if (tid < 64 && STEP == 0) {
-        const int lane = tid;
-        if (MODEL == MLIRT) {
-            // getSubjCoefficientsMlIrt src/Draw.pl.jl:351-357 : beta = (x'x) \ x'theta ; beta[1] = 0 unless intercept
-            if (lane < p) {
-                double t = 0.0;
-                for (int v = 0; v < p; ++v) t += Xinv[lane + v * PMAX] * G0[v];
-                beta[lane] = (lane == 0 && !T.intercept) ? 0.0 : t;
-            }
-        } else if (MODEL == NULLM) {
-            // src/GibbsRtIrt.pl.jl:380: Para.beta = zeros(nFeat+1, 2) every sweep
-            if (lane < 2 * p) { bn[lane] = 0.0; beta[(lane / p) * PMAX + (lane % p)] = 0.0; }
-            if (lane < 8) qf[lane] = 0.0;
-        } else if (MODEL == RTIRT) {
-            // drawSubjCoefficients src/Draw.pl.jl:380-393.  Posterior precision = 11' + kron(inv(Sigp), x'x) (the reference's
-            // `1/sigma^2 .+ M` adds 1 to EVERY element), so by Sherman-Morrison
-            //   parV = Minv - v v'/(1 + 1'v),  Minv = kron(Sigp, (x'x)^-1),  v = Minv 1.
-            const int n = 2 * p;
-            double* V = work, *L = V + n * n, *tv = L + n * n, *vv = tv + n, *rs = vv + n;
-            const double* xt = G0, *xz = G0 + p;
-            const double s00 = Sigp[0], s10 = Sigp[1], s01 = Sigp[2], s11 = Sigp[3];
-            const double sdet = s00 * s11 - s10 * s01;
-            const double iO[4] = { s11 / sdet, -s10 / sdet, -s01 / sdet, s00 / sdet };
-            if (lane < p) { double t = 0.0; for (int w = 0; w < p; ++w) t += Xinv[lane + w * PMAX]; rs[lane] = t; }
-            wave_sync();
-            if (lane < n) {
-                const int a_ = lane / p, u = lane % p;
-                vv[lane] = (Sigp[a_] + Sigp[a_ + 2]) * rs[u];
-                tv[lane] = 0.0 + xt[u] * iO[a_] + xz[u] * iO[a_ + 2];      // vec(x'eta * inv(Sigp)')
-            }
-            wave_sync();
-            double cden = 1.0;
-            for (int i = 0; i < n; ++i) cden += vv[i];
-            for (int e = lane; e < n * n; e += 64) {
-                int i = e % n, jj = e / n;
-                if (i > jj) { const int t_ = i; i = jj; jj = t_; }              // Symmetric(parV): upper triangle
-                const int a_ = i / p, u = i % p, b_ = jj / p, w = jj % p;
-                V[e] = Sigp[a_ + 2 * b_] * Xinv[u + w * PMAX] - vv[i] * vv[jj] / cden;
-            }
-            wave_sync();
-            double pm = 0.0;
-            if (lane < n) for (int jj = 0; jj < n; ++jj) pm += V[lane + jj * n] * tv[jj];
-            chol_lower_wave(n, V, L, lane);
-            const double zi = lane < n ? beta_normal(T.seed, T.chain, sweep, lane) : 0.0;     // z_i drawn by lane i
-            double t = pm;
-            for (int jj = 0; jj < n; ++jj) {
-                const double zj = __shfl(zi, jj, 64);
-                if (lane < n && jj <= lane) t += L[lane + jj * n] * zj;
-            }
-            if (lane < n) {
-                if (!T.intercept && (lane == 0 || lane == p)) t = 0.0;          // src/GibbsRtIrt.pl.jl:293-295
-                bn[lane] = t;
-                beta[(lane / p) * PMAX + (lane % p)] = t;
-            }
-            wave_sync();
-            // quadratic forms needed by Sigma_p: qf[a + 2b] = beta_a' x'x beta_b, qf[4 + a + 2b] = beta_a' x'eta_b; lane f computes form f
-            if (lane < 8) {
-                const int a_ = lane & 1, b_ = (lane >> 1) & 1;
-                double v = 0.0;
-                if (lane < 4) { for (int u = 0; u < p; ++u) for (int w = 0; w < p; ++w) v += bn[a_ * p + u] * XtX[u + w * PMAX] * bn[b_ * p + w]; }
-                else { const double* xe = b_ == 0 ? G0 : G0 + p; for (int u = 0; u < p; ++u) v += bn[a_ * p + u] * xe[u]; }
-                qf[lane] = v;
-            }
-        } else if (MODEL == LATENT) {
-            // drawSubjCoefficientsLatent src/Draw.pl.jl:399-416, x = [1 X theta] (q = p + 1 columns):
-            //   parV = inv(11' + x'x / Sigp22)  (`1/sb0^2 .+ M` adds 1 to EVERY element), parM = parV x'zeta / Sigp22,
-            //   beta = parM + chol(Symmetric(parV)).L z
-            const int q = p + 1;
-            double* Mx = work, *L = Mx + q * q, *V = L + q * q, *tv = V + q * q;
-            const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1; const double tz = G0[2 * p + 1];
-            const double iO = 1.0 / Sigp[3];
-            for (int e = lane; e < q * q; e += 64) {
-                const int i = e % q, jj = e / q;
-                const double a_ = (i < p && jj < p) ? XtX[i + jj * PMAX] : ((i == p && jj == p) ? tt : xt[i < jj ? i : jj]);
-                Mx[e] = 1.0 + iO * a_;
-            }
-            if (lane < q) tv[lane] = 0.0 + (lane < p ? xz[lane] : tz) * iO;
-            wave_sync();
-            chol_lower_wave(q, Mx, L, lane);                     // precision = L L'
-            if (lane < q) {                                      // lane k: column k of the inverse (forward, then backward substitution)
-                const int k = lane;
-                for (int i = 0; i < q; ++i) {
-                    double t = (i == k) ? 1.0 : 0.0;
-                    for (int m = 0; m < i; ++m) t -= L[i + m * q] * V[m + k * q];
-                    V[i + k * q] = t / L[i + i * q];
-                }
-                for (int i = q - 1; i >= 0; --i) {
-                    double t = V[i + k * q];
-                    for (int m = i + 1; m < q; ++m) t -= L[m + i * q] * V[m + k * q];
-                    V[i + k * q] = t / L[i + i * q];
-                }
-            }
-            wave_sync();
-            for (int e = lane; e < q * q; e += 64) {             // Symmetric(parV): upper triangle
-                const int i = e % q, jj = e / q;
-                Mx[e] = V[(i < jj ? i : jj) + (i < jj ? jj : i) * q];
-            }
-            wave_sync();
-            double pm = 0.0;
-            if (lane < q) for (int jj = 0; jj < q; ++jj) pm += Mx[lane + jj * q] * tv[jj];
-            chol_lower_wave(q, Mx, L, lane);
-            const double zi = lane < q ? beta_normal(T.seed, T.chain, sweep, lane) : 0.0;
-            double t = pm;
-            for (int jj = 0; jj < q; ++jj) {
-                const double zj = __shfl(zi, jj, 64);
-                if (lane < q && jj <= lane) t += L[lane + jj * q] * zj;
-            }
-            if (lane < q) {
-                if (!T.intercept && lane == 0) t = 0.0;          // src/GibbsRtIrtLatent.pl.jl:184-186
-                bn[lane] = t; beta[lane] = t;
-            }
-        } else if (MODEL == LATENTQR) {
-            // getSubjCoefficientsLatentQr src/Draw.pl.jl:446-458 : beta = (x'x)^-1 x'(zeta - k1 nu), x = [1 X theta];
-            // block inverse with the constant (X~'X~)^-1 and the Schur complement of the theta column.
-            if (lane == 0) {
-                const int q = p + 1;
-                const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
-                const double tu = G0[2 * p + 1];
-                double* h = work, *g = h + PMAX;
-                double hx = 0.0, hu = 0.0;
-                for (int u = 0; u < p; ++u) {
-                    double t1 = 0.0, t2 = 0.0;
-                    for (int v = 0; v < p; ++v) { t1 += Xinv[u + v * PMAX] * xt[v]; t2 += Xinv[u + v * PMAX] * xu[v]; }
-                    h[u] = t1; g[u] = t2;
-                }
-                for (int u = 0; u < p; ++u) { hx += xt[u] * h[u]; hu += h[u] * xu[u]; }
-                const double b2 = (tu - hu) / (tt - hx);
-                for (int u = 0; u < p; ++u) bn[u] = g[u] - h[u] * b2;
-                bn[p] = b2;
-                if (!T.intercept) bn[0] = 0.0;                                   // src/GibbsRtIrtLatent.pl.jl:288-290
-                for (int u = 0; u < q; ++u) beta[u] = bn[u];
-            }
-        }
-    }
-
-    if (T.dbg_stop == 2) return;
-    // =========================================================== item draws: one thread per item, in waves 2..
-    const int j = tid - 128;
-    if (j >= 0 && j < J) {
-        if (STEP == 0) {
-            const double S0 = st0[0 * J + j], S1 = st0[1 * J + j], S2 = st0[2 * J + j], K1 = st0[3 * J + j];
-            double a = par[j], b = par[J + j];
-            if (fam_cq(MODEL)) {
-                // rho_t: drawSubjCorrCrossQr src/Draw.pl.jl:474-489 / drawSubjCorrCross :463-469 (uses sig2t_{t-1})
-                const double sg = par[3 * J + j];
-                const double R0 = st1[0 * J + j], R1 = st1[1 * J + j];
-                const double parV = 1.0 / (1.0 + R0 / (sg * T.k2));
-                const double parM = parV * (0.0 + R1 / (sg * T.k2));
-                Stream sr(T.seed, T.chain, SITE_RHO, 0u, (uint32_t)j, sweep);
-                par[4 * J + j] = parM + sqrt(parV) * normal<double>(sr);
-            }
-            auto draw_b = [&]() {   // drawItemDifficulty src/Draw.pl.jl:98-105
-                const double parV = 1.0 / (1.0 + a * a * S0);
-                const double parM = parV * (0.0 - (a * K0[j] - a * a * S1));
-                Stream sb(T.seed, T.chain, SITE_B, 0u, (uint32_t)j, sweep);
-                double v = parM + sqrt(parV) * normal<double>(sb);
-                b = v < -4.0 ? -4.0 : (v > 4.0 ? 4.0 : v);
-            };
-            auto draw_a = [&]() {   // drawItemDiscrimination src/Draw.pl.jl:88-93
-                const double parV = 1.0 / (1.0 + (S2 - 2.0 * b * S1 + b * b * S0));
-                const double parM = parV * (1.0 + (K1 - b * K0[j]));
-                Stream sa(T.seed, T.chain, SITE_A, 0u, (uint32_t)j, sweep);
-                a = truncnorm0(sa, parM, sqrt(parV));
-                if (T.onepl) a = 1.0;
-            };
-            if (MODEL == MLIRT) { draw_a(); draw_b(); }   // src/GibbsRtIrt.pl.jl:233-237
-            else { draw_b(); draw_a(); }                  // :301-305
-            par[j] = a; par[J + j] = b;
-        }
-        if ((fam_rt(MODEL) || fam_lq(MODEL)) && STEP == 0) {
-            // lambda: drawItemIntensity src/Draw.pl.jl:215-220 ; sig2t: drawItemTimeResidual :257-262
-            // sum zeta, sum zeta^2 over subjects (RtIrt: (x'zeta)[0] and zz; LatentQr: tracked explicitly)
-            const double sz = fam_rt(MODEL) ? G0[p] : G0[2 * p + 5];
-            const double zz = fam_rt(MODEL) ? G0[2 * p + 2] : G0[2 * p + 6];
-            const double Gj = st0[4 * J + j];
-            const double sg_old = par[3 * J + j];
-            const double parV = 1.0 / (1.0 / (sdLam * sdLam) + Nd / sg_old);
-            const double parM = parV * (muLam / (sdLam * sdLam) + (Nd * cm[j] + sz) / sg_old);
-            Stream sl(T.seed, T.chain, SITE_LAMBDA, 0u, (uint32_t)j, sweep);
-            const double lam = truncnorm0(sl, parM, sqrt(parV));
-            const double lc = lam - cm[j];
-            const double ssq = csq[j] + 2.0 * Gj + zz - 2.0 * lc * sz + Nd * lc * lc;
-            Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
-            const double sg = invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq / 2.0);
-            par[2 * J + j] = lam; par[3 * J + j] = sg;
-            part[j] = 1.0 / sg;
-        }
-        if (fam_cq(MODEL) && STEP == 1) {
-            // lambda: drawItemIntensityCrossQr src/Draw.pl.jl:239-251 / ...Cross :225-231 ; sig2t: drawItemTimeResidualCrossQr :278-288 / ...Cross :267-273
-            const double W0 = st0[4 * J + j], W1 = st0[5 * J + j], W2 = st0[6 * J + j], V = st0[7 * J + j];
-            const double sg_old = par[3 * J + j];
-            const double parV = 1.0 / (1.0 / (sdLam * sdLam) + W0 / (sg_old * T.k2));
-            const double parM = parV * (muLam / (sdLam * sdLam) + (W1 + cm[j] * W0) / (sg_old * T.k2));
-            Stream sl(T.seed, T.chain, SITE_LAMBDA, 0u, (uint32_t)j, sweep);
-            const double lam = truncnorm0(sl, parM, sqrt(parV));
-            const double lc = lam - cm[j];
-            const double ssq = (W2 - 2.0 * lc * W1 + lc * lc * W0) / (2.0 * T.k2);
-            Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
-            const double sg = (MODEL == CROSSQR) ? invgamma(sv, 1e-3 + Nd * 3.0 / 2.0, 1e-3 + ssq + V) : invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq);
-            par[2 * J + j] = lam; par[3 * J + j] = sg;
-            part[j] = 1.0 / sg;
-        }
-        if (MODEL == MLIRT || (fam_cq(MODEL) && STEP == 0)) part[j] = 1.0 / par[3 * J + j];   // sig2t not drawn in this step
-    }
-    __syncthreads();
-
-    if (T.dbg_stop == 3) return;
-    // derived scalar for the row pass: sum_j 1/sig2t_j (fixed order)
-    if (tid == 64) { double t = 0.0; for (int jj = 0; jj < J; ++jj) t += part[jj]; par[par_off_derived(J)] = t; }   // part[j] = 1/sig2t_j (LDS)
-    // =========================================================== Sigma_p_t | beta_t (thread 0; its random numbers were pre-drawn above)
-    if (tid == 0 && STEP == 0 && MODEL != MLIRT) {
-        double S[4] = { 1.0, 0.0, 0.0, 1.0 };
-        if (fam_rt(MODEL)) {
-            // drawSubjCovariance src/Draw.pl.jl:499-515 (Null: drawSubjCovarianceNull :522-535, the same draw with beta = 0) : InverseWishart(N+3, e'e + I), e'e from sufficient statistics
-            // (the quadratic forms beta_a' x'x beta_b and beta_a' x'eta_b were reduced by wave 0 just above: qf[0..7])
-            const double tt = G0[2 * p], tz = G0[2 * p + 1], zz = G0[2 * p + 2];
-            const double* bAb = qf; const double* bx = qf + 4;
-            const double ee00 = tt - 2.0 * bx[0] + bAb[0];
-            const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
-            const double ee11 = zz - 2.0 * bx[3] + bAb[3];
-            const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
-            const double pdet = Psi[0] * Psi[3] - Psi[1] * Psi[2];
-            const double Pi[4] = { Psi[3] / pdet, -Psi[1] / pdet, -Psi[2] / pdet, Psi[0] / pdet };
-            const double l00 = sqrt(Pi[0]), l10 = Pi[1] / l00, l11 = sqrt(Pi[3] - l10 * l10);
-            const double c1 = spd[0], n21 = spd[1], c2 = spd[2];
-            const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
-            const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
-            const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
-            S[0] = Wm[3] / det; S[1] = -Wm[1] / det; S[2] = -Wm[2] / det; S[3] = Wm[0] / det;
-        } else if (MODEL == LATENT) {
-            // drawSubjCovarianceLatent src/Draw.pl.jl:563-579 : InverseGamma(da + N/2, db + sum((zeta - x beta)^2)/2), x = [1 X theta]
-            const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1;
-            const double tz = G0[2 * p + 1], zz = G0[2 * p + 2];
-            double sr2 = zz;
-            for (int u = 0; u < p; ++u) sr2 -= 2.0 * bn[u] * xz[u];
-            sr2 -= 2.0 * bn[p] * tz;
-            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
-            for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
-            sr2 += bn[p] * bn[p] * tt;
-            S[3] = (1e-3 + sr2 / 2.0) / spd[0];
-        } else if (MODEL == LATENTQR) {
-            // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
-            const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
-            const double tu = G0[2 * p + 1], uu = G0[2 * p + 2], snu = G0[2 * p + 3], snu2 = G0[2 * p + 4];
-            double sr2 = uu;
-            for (int u = 0; u < p; ++u) sr2 -= 2.0 * bn[u] * xu[u];
-            sr2 -= 2.0 * bn[p] * tu;
-            for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
-            for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
-            sr2 += bn[p] * bn[p] * tt;
-            const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
-            double quirk = sr2 * sw / sw2;
-            if (T.sigp_mode == 1) {
-                // the evidently intended sum_i r_i^2 / (2 k2 nu_i), r = u - x~ beta, from the 1/nu-weighted Gram statistics
-                const int q = p + 1, ntri = q * (q + 1) / 2;
-                const double* Wg = G0 + 2 * p + 7;
-                double sw_r2 = Wg[ntri + q];
-                for (int u = 0; u < q; ++u) sw_r2 -= 2.0 * bn[u] * Wg[ntri + u];
-                int e = 0;
-                for (int u = 0; u < q; ++u) for (int v = u; v < q; ++v, ++e) sw_r2 += (u == v ? 1.0 : 2.0) * bn[u] * Wg[e] * bn[v];
-                quirk = sw_r2 / (2.0 * T.k2);
-            }
-            const double parB = 1e-3 + quirk + snu;
-            S[3] = parB / spd[0];
-        } else {
-            // drawSubjCovarianceCross src/Draw.pl.jl:542-557
-            const double zz = st1[NSTAT1 * J + 0];
-            S[3] = (1e-3 + zz / 2.0) / spd[0];
-        }
-        if (T.cov2one) d_cov2one(S);
-        for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
-    }
-    __syncthreads();
-
-    if (T.dbg_stop == 4) return;
-    // =========================================================== bookkeeping + item trace
-    const bool last_step = (MODEL != CROSSQR) || STEP == 1;
-    if (last_step && T.tr_item) {
-        const int wrow = 4 * J + T.nq;
-        double* tr = T.tr_item + (size_t)row * wrow;
-        for (int e = tid; e < 4 * J; e += TINY_THREADS) tr[e] = par[e];
-        if (tid < T.nq) {
-            double v;
-            if (MODEL == MLIRT) v = beta[tid];
-            else if (fam_rt(MODEL)) { const int nb = 2 * p; v = tid < nb ? (tid < p ? beta[tid] : beta[PMAX + tid - p]) : Sigp[tid - nb]; }
-            else if (fam_cq(MODEL)) v = tid < J ? par[4 * J + tid] : Sigp[tid - J];
-            else { const int nb = p + 1; v = tid < nb ? beta[tid] : Sigp[tid - nb]; }
-            tr[4 * J + tid] = v;
-        }
-    }
-    for (int e = tid; e < par_size(J); e += TINY_THREADS)
-        if (!(fabs(par[e]) < 1e300)) atomicCAS(&T.ctl->err, 0u, 1u + (uint32_t)e);   // a non-finite entry of the parameter block
-    if (tid == 0 && STEP == 0) { T.ctl->sweep = sweep; T.ctl->row = row; }
+    tiny_draws<MODEL, STEP>(T, lp, st0, st1, part, work, sh_x, sweep);
+    tiny_publish<MODEL, STEP>(T, lp, sweep, row, tid, TINY_THREADS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -338,7 +338,9 @@ __device__ __forceinline__ double gamma_mt(Stream& s, double shape)
         do { x = normal<double>(s); v = 1.0 + c * x; } while (v <= 0.0 && ++tries < MAX_TRIES);
         v = v * v * v;
         const double u = uniform<double>(s);
-        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+        const double x2 = x * x;
+        if (u < 1.0 - 0.0331 * x2 * x2) return d * v;         // Marsaglia-Tsang squeeze: implies the log test below, so it changes no decision
+        if (log(u) < 0.5 * x2 + d - d * v + d * log(v)) return d * v;
         if (tries >= MAX_TRIES) return __builtin_nan("");
     }
 }

@@ -102,8 +102,12 @@ template <typename real> struct Engine : EngineBase {
     int ns[2] = {0, 0};
     uint32_t sweeps_total = 0;
 
-    DevBuf dY, dC, dOmega, dNu, dX, dTheta, dZeta, dPar, dCst, dSlab0, dSlab1, dCtl, dGslab0, dGslab1, dGcnt;
+    DevBuf dY, dC, dOmega, dNu, dX, dTheta, dZeta, dCst, dSlab0, dSlab1, dGslab1, dGcnt;
+    // double-buffered: a fused sweep kernel reads [cur] and writes [1 - cur] (parameter block, counters, group-reduced statistics)
+    DevBuf dParB[2], dCtlB[2], dGslab0B[2];
+    int cur = 0;
     int n_groups = 1;
+    bool fused() const { return !m_cq(); }        // single-pass models run the tiny step inside the row-pass kernel
     DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
 
     ~Engine() override {
@@ -201,6 +205,8 @@ template <typename real> struct Engine : EngineBase {
             rows_per_block = (N + grid_blocks - 1) / grid_blocks;
             grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
             rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
+            // fused sweeps take subjects off wave 0 (it runs the tiny step's structural chain first): the other waves' slices grow
+            if (fused() && nWaves > 1) rows_per_wave = (int)((rows_per_block + nWaves - 2) / (nWaves - 1)) + 1;
             for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
             if (std::max(lds_pass[0], lds_pass[1]) <= 150 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
             grid_blocks *= 2;
@@ -219,15 +225,15 @@ template <typename real> struct Engine : EngineBase {
         if (Fk > 0) rc |= dX.alloc((size_t)N * Fk * sizeof(real));
         rc |= dTheta.alloc((size_t)N * sizeof(real));
         rc |= dZeta.alloc((size_t)N * sizeof(real));
-        rc |= dPar.alloc((size_t)par_size(J) * sizeof(double));
+        for (int k = 0; k < 2; ++k) rc |= dParB[k].alloc((size_t)par_size(J) * sizeof(double));
         rc |= dCst.alloc((size_t)cst_size(J) * sizeof(double));
         n_groups = (grid_blocks + GROUP - 1) / GROUP;
         if (n_groups > TINY_THREADS) return fail(ERM_ERR_ARG, "grid too large");
         rc |= dSlab0.alloc((size_t)grid_blocks * ns[0] * sizeof(double));
-        rc |= dGslab0.alloc((size_t)n_groups * ns[0] * sizeof(double));
+        for (int k = 0; k < 2; ++k) rc |= dGslab0B[k].alloc((size_t)n_groups * ns[0] * sizeof(double));
         rc |= dGcnt.alloc((size_t)2 * n_groups * sizeof(unsigned int));
         if (m_cq()) { rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double)); rc |= dGslab1.alloc((size_t)n_groups * ns[1] * sizeof(double)); }
-        rc |= dCtl.alloc(sizeof(Ctl));
+        for (int k = 0; k < 2; ++k) rc |= dCtlB[k].alloc(sizeof(Ctl));
         rc |= dSumTheta.alloc((size_t)N * sizeof(double));
         rc |= dSumZeta.alloc((size_t)N * sizeof(double));
         if (cfg.model == ERM_MODEL_CROSSQR) rc |= dSumNu.alloc(NJ * sizeof(double));
@@ -258,7 +264,7 @@ template <typename real> struct Engine : EngineBase {
         for (int j = 0; j < J; ++j) { par[j] = 1.0; par[3 * J + j] = 1.0; }
         par[par_off_sigp(J) + 0] = 1.0; par[par_off_sigp(J) + 3] = 1.0;
         par[par_off_derived(J)] = (double)J;
-        HIPCHK(hipMemcpy(dPar.p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
+        for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpy(dParB[k].p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
         if (dNu.p) {
             std::vector<real> ones(dNu.bytes / sizeof(real), real(1));
             HIPCHK(hipMemcpy(dNu.p, ones.data(), dNu.bytes, hipMemcpyHostToDevice));
@@ -269,41 +275,48 @@ template <typename real> struct Engine : EngineBase {
     }
 
     // -------------------------------------------------------------------------------------------- kernels
-    template <int MODEL, int PHASE> int set_lds_attr(size_t bytes) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<MODEL, real, PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    template <int MODEL, int PHASE, bool FUSED> int set_lds_attr(size_t bytes) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<MODEL, real, PHASE, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         return 0;
     }
+    // the fused kernel appends the tiny step's scratch (statistics, partials, structural scratch, x'x, parameter block) to the pass layout
+    size_t fused_lds() const { return lds_pass[0] + 8 + (size_t)(2 * ns[0] + TINY_WORK + 2 * PMAX * PMAX + par_size(J) + 3 * J + 2) * sizeof(double); }
     size_t tiny_lds() const {
         const int mx = std::max(ns[0], ns[1]);
-        return (size_t)(ns[0] + (m_cq() ? ns[1] : 0) + 4 * mx + TINY_WORK + 2 * PMAX * PMAX) * sizeof(double);
+        return (size_t)(ns[0] + (m_cq() ? ns[1] : 0) + 4 * mx + TINY_WORK + 2 * PMAX * PMAX + par_size(J)) * sizeof(double);
     }
     int configure_kernels() {
         const int tl = (int)tiny_lds();
         if (tl > 160 * 1024) return fail(ERM_ERR_ARG, "tiny-step LDS footprint too large");
         return dispatch([&](auto m) -> int {
             constexpr int M = decltype(m)::value;
-            if (int rc = set_lds_attr<M, 0>(lds_pass[0])) return rc;
+            if (int rc = set_lds_attr<M, 0, false>(lds_pass[0])) return rc;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<M, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
+            if constexpr (!fam_cq(M)) {
+                if (fused_lds() > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads or raise grid_blocks");
+                if (int rc = set_lds_attr<M, 0, true>(fused_lds())) return rc;
+            }
             if constexpr (fam_cq(M)) {
-                if (int rc = set_lds_attr<M, 1>(lds_pass[1])) return rc;
+                if (int rc = set_lds_attr<M, 1, false>(lds_pass[1])) return rc;
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<M, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
             }
             return 0;
         });
     }
 
-    PassArgs<real> pass_args(int phase, int mode) const {
+    PassArgs<real> pass_args(int phase, int mode, bool fz = false) const {
         PassArgs<real> a{};
         a.Y = dY.as<uint8_t>(); a.C = dC.as<real>(); a.omega = dOmega.as<real>(); a.nu = dNu.as<real>(); a.X = dX.as<real>();
         a.theta = dTheta.as<real>(); a.zeta = dZeta.as<real>();
-        a.par = dPar.as<double>(); a.cst = dCst.as<double>();
+        a.par = dParB[cur].template as<double>(); a.cst = dCst.as<double>();
         a.slab = phase == 0 ? dSlab0.as<double>() : dSlab1.as<double>();
-        a.gslab = phase == 0 ? dGslab0.as<double>() : dGslab1.as<double>();
+        a.gslab = phase == 0 ? dGslab0B[fz ? 1 - cur : cur].template as<double>() : dGslab1.as<double>();
         a.gcnt = dGcnt.as<unsigned int>() + (phase == 0 ? 0 : n_groups);
-        a.ctl = dCtl.as<Ctl>();
+        a.ctl = dCtlB[cur].template as<Ctl>();
         a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
         a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
         a.N = N; a.rows_per_block = rows_per_block; a.rows_per_wave = rows_per_wave; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode; a.ngx = phase == 0 ? ngx() : 0;
+        { const char* e = getenv("ERM_SKEW"); a.skew = fz ? (e ? atoi(e) : 2) : 0; }
         a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
@@ -311,11 +324,13 @@ template <typename real> struct Engine : EngineBase {
         { const char* e = getenv("ERM_PASS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
         return a;
     }
-    TinyArgs tiny_args(int mode, int first) const {
+    TinyArgs tiny_args(int mode, int first, bool fz = false) const {
         TinyArgs t{};
-        t.par = dPar.as<double>(); t.cst = dCst.as<double>(); t.slab0 = dGslab0.as<double>(); t.slab1 = dGslab1.as<double>();
-        t.gcnt0 = dGcnt.as<unsigned int>(); t.gcnt1 = dGcnt.as<unsigned int>() + n_groups;
-        t.ctl = dCtl.as<Ctl>(); t.tr_item = dTrItem.as<double>(); t.tr_ll = dTrLl.as<double>();
+        const int o = fz ? 1 - cur : cur;
+        t.par = dParB[cur].template as<double>(); t.par_out = dParB[o].template as<double>();
+        t.cst = dCst.as<double>(); t.slab0 = dGslab0B[cur].template as<double>(); t.slab1 = dGslab1.as<double>();
+        t.ctl = dCtlB[cur].template as<Ctl>(); t.ctl_out = dCtlB[o].template as<Ctl>(); t.ctl_err = dCtlB[0].template as<Ctl>();
+        t.tr_item = dTrItem.as<double>(); t.tr_ll = dTrLl.as<double>();
         t.N = N; t.J = J; t.nFeat = Fk; t.nb0 = n_groups; t.nb1 = n_groups; t.mode = mode; t.first = first;
         t.intercept = cfg.intercept; t.onepl = cfg.one_pl; t.cov2one = cfg.cov2one; t.sigp_mode = cfg.sigp_mode;
         t.chain = (uint32_t)cfg.chain_id; t.seed = cfg.seed;
@@ -330,10 +345,22 @@ template <typename real> struct Engine : EngineBase {
     int64_t n_pass_timed = 0;
     template <int MODEL, int PHASE> int launch_pass(int mode, bool timed) {
         PassArgs<real> a = pass_args(PHASE, mode);
+        TinyArgs t{};
         const bool ev = timed && cfg.profile && (size_t)(2 * n_pass_timed + 1) + 64 < pass_ev.size();
         if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed], stream));
-        hipLaunchKernelGGL((pass_kernel<MODEL, real, PHASE>), dim3(grid_blocks), dim3(block_threads), lds_pass[PHASE], stream, a);
+        hipLaunchKernelGGL((pass_kernel<MODEL, real, PHASE, false>), dim3(grid_blocks), dim3(block_threads), lds_pass[PHASE], stream, a, t);
         if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed + 1], stream)); ++n_pass_timed; }
+        return 0;
+    }
+    // one whole sweep of a single-pass model: tiny step + row pass in one launch; reads buffers [cur], writes [1 - cur]
+    template <int MODEL> int launch_fused(bool first, bool timed) {
+        PassArgs<real> a = pass_args(0, 1, true);
+        TinyArgs t = tiny_args(0, first ? 1 : 0, true);
+        const bool ev = timed && cfg.profile && (size_t)(2 * n_pass_timed + 1) + 64 < pass_ev.size();
+        if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed], stream));
+        hipLaunchKernelGGL((pass_kernel<MODEL, real, 0, true>), dim3(grid_blocks), dim3(block_threads), fused_lds(), stream, a, t);
+        if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed + 1], stream)); ++n_pass_timed; }
+        cur ^= 1;
         return 0;
     }
     template <int MODEL, int STEP> int launch_tiny(int mode, int first) {
@@ -349,6 +376,7 @@ template <typename real> struct Engine : EngineBase {
     static constexpr int PROFILE_STRIDE = 8;
     hipGraphExec_t graph_exec = nullptr;
     template <int MODEL> int enqueue_sweep(bool first, bool timed) {
+        if constexpr (!fam_cq(MODEL)) return launch_fused<MODEL>(first, timed);
         if (int rc = launch_tiny<MODEL, 0>(0, first)) return rc;
         if (int rc = launch_pass<MODEL, 0>(1, timed)) return rc;
         if constexpr (fam_cq(MODEL)) {
@@ -394,7 +422,12 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipSetDevice(cfg.device));
         Ctl c{};
         c.sweep = sweeps_total; c.row = (uint32_t)rows_done; c.burn_rows = (uint32_t)((int64_t)cfg.n_burnin * cfg.n_chain); c.err = 0;
-        HIPCHK(hipMemcpyAsync(dCtl.p, &c, sizeof(Ctl), hipMemcpyHostToDevice, stream));
+        if (cur == 1) {      // every run starts from buffer 0 so that a captured graph always replays with the buffer parity it was built with
+            HIPCHK(hipMemcpyAsync(dParB[0].p, dParB[1].p, dParB[0].bytes, hipMemcpyDeviceToDevice, stream));
+            cur = 0;
+        }
+        for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpyAsync(dCtlB[k].p, &c, sizeof(Ctl), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemsetAsync(dGcnt.p, 0, dGcnt.bytes, stream));
         n_pass_timed = 0;
         if (cfg.profile && pass_ev.size() >= 64) {   // empty event pairs: the bracketing overhead that is subtracted from every timed launch
             for (int k = 0; k < 16; ++k) { HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 2 - 2 * k], stream)); HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 1 - 2 * k], stream)); }
@@ -418,8 +451,12 @@ template <typename real> struct Engine : EngineBase {
             HIPCHK(hipEventElapsedTime(&t, pass_ev[2 * k], pass_ev[2 * k + 1]));
             timing.pass_ms_total += std::max(0.0, (double)t - null_ms);
         }
-        Ctl back{};
-        HIPCHK(hipMemcpy(&back, dCtl.p, sizeof(Ctl), hipMemcpyDeviceToHost));
+        Ctl back{}, back0{};
+        HIPCHK(hipMemcpy(&back, dCtlB[cur].p, sizeof(Ctl), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&back0, dCtlB[0].p, sizeof(Ctl), hipMemcpyDeviceToHost));
+        back.err = back0.err;
+        if (cur != 0) { Ctl b1{}; HIPCHK(hipMemcpy(&b1, dCtlB[1 - cur].p, sizeof(Ctl), hipMemcpyDeviceToHost)); back.dbg_attempts += b1.dbg_attempts; back.dbg_trips += b1.dbg_trips; back.dbg_cells += b1.dbg_cells; }
+        else { Ctl b1{}; HIPCHK(hipMemcpy(&b1, dCtlB[1].p, sizeof(Ctl), hipMemcpyDeviceToHost)); back.dbg_attempts += b1.dbg_attempts; back.dbg_trips += b1.dbg_trips; back.dbg_cells += b1.dbg_cells; }
         const int64_t burn = (int64_t)cfg.n_burnin * cfg.n_chain;
         const int64_t lo = std::max<int64_t>(rows_done, burn), hi = rows_done + nsweeps;
         if (hi > lo) post_rows += hi - lo;
@@ -554,7 +591,7 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamSynchronize(stream));
         std::vector<double> par(par_size(J));
-        HIPCHK(hipMemcpy(par.data(), dPar.p, par.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(par.data(), dParB[cur].p, par.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (st->a) memcpy(&par[0], st->a, J * sizeof(double));
         if (st->b) memcpy(&par[J], st->b, J * sizeof(double));
         if (st->lambda) memcpy(&par[2 * J], st->lambda, J * sizeof(double));
@@ -568,7 +605,7 @@ template <typename real> struct Engine : EngineBase {
             else if (cfg.model != ERM_MODEL_NULL) for (int u = 0; u < nbeta(); ++u) b[u] = st->beta[u];
         }
         { double t = 0.0; for (int j = 0; j < J; ++j) t += 1.0 / par[3 * J + j]; par[par_off_derived(J)] = t; }
-        HIPCHK(hipMemcpy(dPar.p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dParB[cur].p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
         if (st->theta) if (int rc = up_real(dTheta, st->theta, N)) return rc;
         if (st->zeta) if (int rc = up_real(dZeta, st->zeta, N)) return rc;
         if (st->nu && dNu.p) {
@@ -591,7 +628,7 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamSynchronize(stream));
         std::vector<double> par(par_size(J));
-        HIPCHK(hipMemcpy(par.data(), dPar.p, par.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(par.data(), dParB[cur].p, par.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (st->a) memcpy(st->a, &par[0], J * sizeof(double));
         if (st->b) memcpy(st->b, &par[J], J * sizeof(double));
         if (st->lambda) memcpy(st->lambda, &par[2 * J], J * sizeof(double));
