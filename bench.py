@@ -27,7 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-ALGO_BYTES = {"mlirt": 9, "rtirt": 13, "latentqr": 13, "crossqr": 29}   # fp32 matrices, Y as 1 byte
+ALGO_BYTES = {"mlirt": 9, "rtirt": 13, "latentqr": 13, "crossqr": 29,          # fp32 matrices, Y as 1 byte
+              "null": 13, "latent": 13, "cross": 17}                        # variants: as their families; Cross: omega r/w, Y, logT twice, no nu
+FAMILY = {"null": "rtirt", "latent": "latentqr", "cross": "crossqr"}
 HBM_PEAK_GBS = 8000.0                                                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -37,6 +39,7 @@ def make_data(pkg, model, N, J, F, seed):
     if model == "mlirt":
         tp = pkg.setTrueParaMlIrt(Cond, seed=g); D = pkg.setDataMlIrt(Cond, tp, seed=g)
         return D.Y, None, D.X
+    model = FAMILY.get(model, model)
     if model == "rtirt":
         tp = pkg.setTrueParaRtIrt(Cond, seed=g); D = pkg.setDataRtIrt(Cond, tp, seed=g)
         return D.Y, D.logT, D.X
@@ -56,8 +59,10 @@ def init_state(model, N, J, F, rank):
         st["beta"] = g.standard_normal(F + 1)
     elif model == "rtirt":
         st["beta"] = g.standard_normal((F + 1, 2))
-    elif model == "latentqr":
+    elif model in ("latentqr", "latent"):
         st["beta"] = g.standard_normal(F + 2)
+    elif model == "null":
+        pass
     else:
         st["rho"] = g.standard_normal(J)
     return st
@@ -69,7 +74,7 @@ def cpu_baseline(model, Y, logT, X, st, sweeps, threads=1):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity_util as pu
     pu.oracle().orc_set_threads(int(threads))
-    op = pu.OracleProblem(model, Y, logT, X, st, qRt=0.85, cov2one=(model != "latentqr"))
+    op = pu.OracleProblem(model, Y, logT, X, st, qRt=0.85, cov2one=(model not in ("latentqr", "latent")))
     op.run(1)                       # warm-up sweep (page in, first omega)
     t0 = time.perf_counter()
     op.run(sweeps)
@@ -131,7 +136,7 @@ def main():
     st = init_state(model, N, J, F, rank)
     rows = args.warmup + args.steps
     eng = L.Engine(model=getattr(L, "MODEL_" + model.upper()), n_item=J, n_subj=N, n_feat=0 if X is None else F, n_iter=rows, n_chain=1,
-                   n_burnin=args.warmup, cov2one=int(model != "latentqr"), q_rt=0.85, seed=1234, chain_id=rank, device=local_rank,
+                   n_burnin=args.warmup, cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, chain_id=rank, device=local_rank,
                    precision=L.PREC_F32 if args.precision == "f32" else L.PREC_F64,
                    trace_mode=L.TRACE_FULL if args.trace == "full" else L.TRACE_SUMMARY, lanes_per_row=args.lanes_per_row,
                    block_threads=args.block_threads, grid_blocks=args.grid_blocks, profile=0 if args.no_profile else 1)
@@ -177,7 +182,7 @@ def main():
             "metric": "Gibbs cell-updates/s (nSubj x nItem x sweeps/s)", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"Gibbs{ {'mlirt': 'MlIrt', 'rtirt': 'RtIrt', 'latentqr': 'RtIrtLatentQr', 'crossqr': 'RtIrtCrossQr'}[model] } "
+            "config": {"workload": f"Gibbs{ {'mlirt': 'MlIrt', 'rtirt': 'RtIrt', 'latentqr': 'RtIrtLatentQr', 'crossqr': 'RtIrtCrossQr', 'null': 'RtIrtNull', 'cross': 'RtIrtCross', 'latent': 'RtIrtLatent'}[model] } "
                                    f"nSubj={N} nItem={J} nFeat={F} nChain=1 per GPU (BASELINE.json configs[2])",
                        "chains": world, "trace": args.trace, "lanes_per_row": tm["lanes_per_row"], "block_threads": tm["block_threads"],
                        "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"]},
@@ -187,7 +192,7 @@ def main():
             out["gather_ms"] = gather_ms
         if tm["pass_launches"] > 0:
             per_launch_s = tm["pass_ms_total"] / tm["pass_launches"] * 1e-3
-            launches_per_sweep = 2 if model == "crossqr" else 1
+            launches_per_sweep = 2 if model in ("crossqr", "cross") else 1
             algo = ALGO_BYTES[model] * cells / launches_per_sweep
             ach = algo / per_launch_s / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

@@ -80,6 +80,7 @@ template <typename real> struct PassArgs {
     int skew;             // FUSED kernels: subjects taken off wave 0's slice (it runs the structural chain of the tiny step first)
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // diagnostics only: skip everything after stage k (0 = run everything)
+    unsigned long long* dbg_ts;   // diagnostics only (ERM_TIMELINE): [2 workgroups][16 waves][16 checkpoints] of the 100 MHz wall clock
 };
 
 // Lanes of ONE wave exchange data through LDS: DS instructions of a wave execute in order, so a compiler-level fence is all
@@ -608,6 +609,17 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     const int NV = A.nFeat + 4;
     real* sh_val = sh_item + NITEMARR * J + (size_t)nWaves * 4 * A.rows_per_wave;   // [rows_per_block][NV] per-subject values of the global statistics
 
+    // diagnostics: per-wave phase timeline of workgroups 0 and gridDim/2 (lane 0 of each wave stamps the constant-rate wall clock)
+    // (compiled in only with -DERM_TIMELINE_BUILD: even the disabled checks cost registers and ~3 us per sweep)
+    auto stamp = [&](int k) {
+#ifdef ERM_TIMELINE_BUILD
+        if (A.dbg_ts && lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && wave < 16)
+            A.dbg_ts[((blockIdx.x == 0 ? 0 : 1) * 16 + wave) * 16 + k] = wall_clock64();
+#else
+        (void)k;
+#endif
+    };
+    stamp(0);
     const uint8_t* __restrict__ gY = A.Y;
     const real* __restrict__ gC = A.C;
     const real* __restrict__ gX = A.X;
@@ -631,6 +643,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         for (int e = tid; e < 3 * J + 2; e += nthr) lcst[e] = T.cst[e];
         reduce_rows(T.slab0, T.nb0, NS0, st0, tid, nthr);
         __syncthreads();
+        stamp(1);
         if (A.dbg_stop == 30) return;
         const uint32_t prev_row = T.ctl->row;
         sweep = T.ctl->sweep + 1u;
@@ -664,6 +677,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     for (int e = threadIdx.x; e < nWaves * NG; e += blockDim.x) sh_gacc[e] = 0.0;
     __syncthreads();
 
+    stamp(2);
     if (A.dbg_stop == 32) return;
     if constexpr (FUSED) {
         if (wave == 0) {
@@ -682,6 +696,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             if (writer) tiny_publish<MODEL, 0>(T, lp, sweep, trow, lane, 64);
         }
     }
+    stamp(3);
     const real k1 = (real)A.k1, k2 = (real)A.k2;
     double* acc = sh_acc + (size_t)wave * NSTAT * J;
     double ll = 0.0;
@@ -749,6 +764,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         }
     }
     wave_sync();
+    stamp(4);
     if (A.dbg_stop == 5) return;
 
     // =================================================================================================== phase 1 (ii)
@@ -758,6 +774,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         while (__hip_atomic_load(sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    stamp(5);
     const real sig11 = (MODEL == MLIRT) ? real(1) : (real)sh_struct[0];
     const real sig22 = (real)sh_struct[3];
     const real sum_isig = (real)sh_struct[4];
@@ -878,6 +895,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             o[F] = th; o[F + 1] = ze; o[F + 2] = ze - k1 * nu_next; o[F + 3] = nu_next;
         }
     }
+    stamp(6);
     if (A.dbg_stop == 2) return;
 
     // ---------------- omega_{t+1} | theta_t, a_t, b_t  (src/Draw.pl.jl:36-40), persistent lanes over the wave's flattened cells:
@@ -909,6 +927,9 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         real* om = A.omega + (size_t)ra * J;
         const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
         unsigned int n_att = 0, n_trip = 0;
+        // (letting a wave whose queue ran dry serve other waves' queues was tried: the hardware favours a SIMD's oldest wave, so the
+        // four waves of a SIMD finish up to 17 us apart -- but the phase is VALU-throughput-bound, the SIMD is busy until the last
+        // one ends either way, and the stealing logic only added instructions: 78.5 vs 75.3 us per sweep)
         while (__any(active)) {
             ++n_trip; n_att += active ? 1u : 0u;
             if (active) {
@@ -931,8 +952,10 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             if (lane == 0) { atomicAdd(&cw->dbg_trips, (unsigned long long)n_trip); atomicAdd(&cw->dbg_cells, (unsigned long long)ncell); }
         }
     }
+    stamp(7);
     if (A.dbg_stop == 3) return;
     __syncthreads();
+    stamp(8);
 
     // ---- global statistics for the next tiny step: statistic g = sum over the workgroup's subjects of va * vb (* 1/nu for the
     // sigp_mode-1 block); 32 lanes per statistic, lane l sums subjects l, l+32, ... in order, then a 32-lane butterfly: fixed order
@@ -980,6 +1003,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         }
     }
 
+    stamp(9);
     // =================================================================================================== phase 2
     // lane = item j; the waves stride over the workgroup's subjects; accumulators live in fp64 registers
     for (int cb = 0; cb * 64 < J && A.dbg_stop != 7; ++cb) {
@@ -1008,6 +1032,11 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
                 nv[u] = (MODEL == CROSSQR) ? A.nu[e] : real(1);
             }
+            // the 4 cells of a batch are summed in `real` and enter the fp64 accumulators once per batch (fp64 VALU work is what bounds
+            // this phase; a 4-term fp32 sum costs ~1 ulp of its terms' own rounding)
+            real bs[NSTAT]; real bl = real(0);
+#pragma unroll
+            for (int q = 0; q < NSTAT; ++q) bs[q] = real(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (!okv[u]) continue;
@@ -1018,9 +1047,9 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     const real w = wv[u];
                     const bool y = yv[u];
                     const real c = cv[u];
-                    const double wd = (double)w, thd = (double)th;
-                    S[0] += wd; S[1] += wd * thd; S[2] += wd * thd * thd; S[3] += y ? 0.5 * thd : -0.5 * thd;
-                    if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) S[4] += (double)c * (double)ze;
+                    const real wt = w * th;
+                    bs[0] += w; bs[1] += wt; bs[2] += wt * th; bs[3] += y ? real(0.5) * th : real(-0.5) * th;
+                    if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) bs[4] += c * ze;
                     if (A.mode == 1) {
                         const real eta = a * (th - b);
                         real t = (y ? eta : real(0)) - log1pexp_r(eta);
@@ -1028,14 +1057,14 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                             const real er = c + ze - lamc;
                             t += real(-0.5) * ((real)LOG_2PI + lsig + er * er * isig);
                         }
-                        llc += (double)t;
+                        bl += t;
                     }
                     if constexpr (fam_cq(MODEL)) {
                         // statistics for lambda_t, sig2t_t (src/Draw.pl.jl:246-247, 285) with nu_t, zeta_{t-1}, theta_t, rho_t
                         const real nu = nv[u];
                         const real rr = c + ze + th * rho - k1 * nu;
-                        const double inu = 1.0 / (double)nu, rd = (double)rr;
-                        S[4] += inu; S[5] += rd * inu; S[6] += rd * rd * inu; S[7] += (double)nu;
+                        const real inu = r_rcp(nu), ri = rr * inu;
+                        bs[4] += inu; bs[5] += ri; bs[6] += rr * ri; bs[7] += nu;
                     }
                 } else {
                     // CrossQr pass B: RT log-likelihood with nu_t, then nu_{t+1} (src/Draw.pl.jl:303-320) and rho statistics (:484-485)
@@ -1044,7 +1073,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     if (A.mode == 1) {
                         const real var_ = k2 * nu;                               // times sig2t_j
                         const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
-                        llc += (double)(real(-0.5) * ((real)LOG_2PI + lsig + r_log(var_) + r_div(er * er * isig, var_)));
+                        bl += real(-0.5) * ((real)LOG_2PI + lsig + r_log(var_) + r_div(er * er * isig, var_));
                         if (has_nu(MODEL) && post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
                         if (has_nu(MODEL) && A.tr_nu) A.tr_nu[(size_t)trow * (size_t)A.N * J + e] = nu;     // Post.qr's vec(nu_t) (src/GibbsRtIrtCross.pl.jl:296)
                     }
@@ -1057,11 +1086,14 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                         nun = qr_weight<real>(st, parA, parB);
                         A.nu[e] = nun;
                     }
-                    const double inu = 1.0 / (double)nun, thd = (double)th;
-                    S[0] += thd * thd * inu;
-                    S[1] += thd * (double)(lamc - ze - c + k1 * nun) * inu;
+                    const real ti = th * r_rcp(nun);
+                    bs[0] += th * ti;
+                    bs[1] += (lamc - ze - c + k1 * nun) * ti;
                 }
             }
+#pragma unroll
+            for (int q = 0; q < NSTAT; ++q) S[q] += (double)bs[q];
+            llc += (double)bl;
         }
         if (jv) {
 #pragma unroll
@@ -1070,6 +1102,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         ll += llc;
     }
 
+    stamp(10);
     if (A.dbg_stop == 4) return;
 
     // ---------------- block epilogue: fixed-order reduction of the wave accumulators into this block's slab row
@@ -1092,6 +1125,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     // because each workgroup has just dirtied its whole omega slice.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(11);
     int* sh_flag = reinterpret_cast<int*>(sh_struct);       // sh_struct is dead by now
     const int grp = blockIdx.x / GROUP;
     const int gfirst = grp * GROUP;
@@ -1106,6 +1140,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
         sh_flag[0] = last;
     }
     __syncthreads();
+    stamp(12);
     if (sh_flag[0]) {
         double* gout = A.gslab + (size_t)grp * NS;
         for (int e = threadIdx.x; e < NS; e += blockDim.x) {
@@ -1118,6 +1153,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             gout[e] = t;
         }
     }
+    stamp(13);
 }
 
 constexpr int tiny_lds_doubles(int NS0, int NS1, int J) { return NS0 + NS1 + 4 * (NS0 > NS1 ? NS0 : NS1) + TINY_WORK + 2 * PMAX * PMAX + par_size(J); }

@@ -105,6 +105,7 @@ template <typename real> struct Engine : EngineBase {
     DevBuf dY, dC, dOmega, dNu, dX, dTheta, dZeta, dCst, dSlab0, dSlab1, dGslab1, dGcnt;
     // double-buffered: a fused sweep kernel reads [cur] and writes [1 - cur] (parameter block, counters, group-reduced statistics)
     DevBuf dParB[2], dCtlB[2], dGslab0B[2];
+    DevBuf dDbgTs;                                   // ERM_TIMELINE diagnostics
     int cur = 0;
     int n_groups = 1;
     bool fused() const { return !m_cq(); }        // single-pass models run the tiny step inside the row-pass kernel
@@ -253,6 +254,7 @@ template <typename real> struct Engine : EngineBase {
                 if (need_gb <= cap_gb) rc |= dTrNu.alloc((size_t)rows_cap * NJ * sizeof(real));
             }
         }
+        if (getenv("ERM_TIMELINE")) rc |= dDbgTs.alloc(2 * 16 * 16 * sizeof(unsigned long long));
         if (rc) return rc;
         if (cfg.profile) {
             pass_ev.resize(2 * 4096);
@@ -322,6 +324,7 @@ template <typename real> struct Engine : EngineBase {
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
         if (!m_nu()) { a.k1 = 0.0; a.k2 = 1.0; }                                   // no quantile weights: nu == 1, k1 = 0, k2 = 1
         { const char* e = getenv("ERM_PASS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
+        a.dbg_ts = dDbgTs.as<unsigned long long>();
         return a;
     }
     TinyArgs tiny_args(int mode, int first, bool fz = false) const {
@@ -465,6 +468,23 @@ template <typename real> struct Engine : EngineBase {
         if (getenv("ERM_PASS_STOP") && atoi(getenv("ERM_PASS_STOP")) == 9)
             fprintf(stderr, "[erm dbg] attempts %llu cells %llu wave-trips %llu -> attempts/cell %.4f, lane efficiency %.4f\n", back.dbg_attempts, back.dbg_cells, back.dbg_trips,
                     (double)back.dbg_attempts / (double)back.dbg_cells, (double)back.dbg_attempts / (64.0 * (double)back.dbg_trips));
+        if (dDbgTs.p) {      // per-wave phase timeline of the LAST launch (us since the workgroup's first stamp)
+            std::vector<unsigned long long> ts(2 * 16 * 16);
+            HIPCHK(hipMemcpy(ts.data(), dDbgTs.p, ts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            static const char* names[14] = {"start", "B1", "B3", "struct", "sums", "ready", "draws", "PG", "barrier", "gstats", "phase2", "slab", "ticket", "end"};
+            for (int b = 0; b < 2; ++b) {
+                unsigned long long t0 = ~0ull;
+                for (int w = 0; w < 16; ++w) if (ts[(b * 16 + w) * 16] && ts[(b * 16 + w) * 16] < t0) t0 = ts[(b * 16 + w) * 16];
+                fprintf(stderr, "[erm timeline] workgroup %s\n  wave", b == 0 ? "0" : "grid/2");
+                for (int k = 0; k < 14; ++k) fprintf(stderr, " %7s", names[k]);
+                fprintf(stderr, "\n");
+                for (int w = 0; w < 16; ++w) {
+                    fprintf(stderr, "  %4d", w);
+                    for (int k = 0; k < 14; ++k) { const unsigned long long v = ts[(b * 16 + w) * 16 + k]; fprintf(stderr, " %7.2f", v ? (double)(v - t0) * 0.01 : -1.0); }
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
         if (back.err) {
             const int e = (int)back.err - 1;
             const char* names[] = {"a", "b", "lambda", "sig2t", "rho"};
