@@ -214,7 +214,7 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
     const int tid = threadIdx.x, nthreads = blockDim.x;
     //   RtIrt   : c1^2 ~ chi2(N+3), n21 ~ N(0,1), c2^2 ~ chi2(N+2) (Bartlett factor of the Wishart; same stream order as the oracle)
     //   others  : g ~ Gamma(shape) of the InverseGamma
-    if (tid == 64 && STEP == 0 && MODEL != MLIRT) {
+    if (tid == (nthreads > 64 ? 64 : 0) && STEP == 0 && MODEL != MLIRT) {
         Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
         if (fam_rt(MODEL)) {
             const double df = Nd + 3.0;
@@ -227,9 +227,11 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
     }
     // =========================================================== item draws: one thread per item, in waves 2..; when the workgroup has
     // enough threads the response-time draws (lambda, sig2t) of an item run on a second thread, concurrently with its (b, a) draws
-    const int nit = nthreads - 128;
+    // (a workgroup of fewer than 256 threads has no waves to spare: every thread takes items)
+    const int ioff = nthreads >= 256 ? 128 : 0;
+    const int nit = nthreads - ioff;
     const int rt_off = (nit >= 2 * J) ? J : 0;
-    for (int j = tid - 128; tid >= 128 && j < J; j += (rt_off ? 2 * J : nit)) {
+    for (int j = tid - ioff; tid >= ioff && j < J; j += (rt_off ? 2 * J : nit)) {
         if (STEP == 0) {
             const double S0 = st0[0 * J + j], S1 = st0[1 * J + j], S2 = st0[2 * J + j], K1 = st0[3 * J + j];
             double a = par[j], b = par[J + j];
@@ -261,7 +263,7 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
             par[j] = a; par[J + j] = b;
         }
     }
-    for (int j = tid - 128 - rt_off; tid >= 128 + rt_off && j < J; j += (rt_off ? 2 * J : nit)) {
+    for (int j = tid - ioff - rt_off; tid >= ioff + rt_off && j < J; j += (rt_off ? 2 * J : nit)) {
         if ((fam_rt(MODEL) || fam_lq(MODEL)) && STEP == 0) {
             // lambda: drawItemIntensity src/Draw.pl.jl:215-220 ; sig2t: drawItemTimeResidual :257-262
             // sum zeta, sum zeta^2 over subjects (RtIrt: (x'zeta)[0] and zz; LatentQr: tracked explicitly)

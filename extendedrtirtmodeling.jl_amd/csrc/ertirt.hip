@@ -209,7 +209,8 @@ template <typename real> struct Engine : EngineBase {
             // fused sweeps take subjects off wave 0 (it runs the tiny step's structural chain first): the other waves' slices grow
             if (fused() && nWaves > 1) rows_per_wave = (int)((rows_per_block + nWaves - 2) / (nWaves - 1)) + 1;
             for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
-            if (std::max(lds_pass[0], lds_pass[1]) <= 150 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
+            const size_t need_lds = std::max(std::max(lds_pass[0], lds_pass[1]), fused() ? fused_lds() : (size_t)0);
+            if (need_lds <= 158 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
             grid_blocks *= 2;
         }
         if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads or raise grid_blocks");

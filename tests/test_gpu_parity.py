@@ -57,6 +57,21 @@ def test_latentqr_intended_sigp_scale(F):
     assert not np.allclose(res["dev_qr"][:, F + 2 + 3], ref["dev_qr"][:, F + 2 + 3])        # Sigp[2,2] differs between the modes
 
 
+@pytest.mark.parametrize("model", ["mlirt", "rtirt", "latent", "cross"])
+def test_f64_single_wave_workgroups(model):
+    """block_threads = 64: one wave does everything (item draws, structural chain, Sigma_p variates, rows)."""
+    res = pu.run_pair(model, N=333, J=9, nsweeps=4, precision="f64", block_threads=64, grid_blocks=7)
+    assert pu.max_rel_err(res) < 1e-8
+
+
+@pytest.mark.parametrize("model", ["rtirt", "latentqr", "crossqr"])
+def test_f64_more_workgroups_than_compute_units(model):
+    """A grid larger than the chip: late workgroups start after early ones have finished and published this sweep's parameter
+    block, statistics and counters -- the fused sweep kernel's inputs are double-buffered, so they must still read last sweep's."""
+    res = pu.run_pair(model, N=6000, J=7, nsweeps=3 if model == "crossqr" else 6, precision="f64", block_threads=128, grid_blocks=1500)
+    assert pu.max_rel_err(res) < 1e-8
+
+
 @pytest.mark.parametrize("J,N", [(1, 50), (64, 130), (65, 70), (130, 40)])
 def test_f64_ragged_shapes(J, N):
     res = pu.run_pair("rtirt", N=N, J=J, nsweeps=4, precision="f64")
