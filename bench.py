@@ -25,6 +25,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # the oracle's OpenMP threads must not spin on a shared host
 import __graft_entry__ as ge  # noqa: E402
 
 ALGO_BYTES = {"mlirt": 9, "rtirt": 13, "latentqr": 13, "crossqr": 29,          # fp32 matrices, Y as 1 byte
@@ -68,18 +69,40 @@ def init_state(model, N, J, F, rank):
     return st
 
 
-def cpu_baseline(model, Y, logT, X, st, sweeps, threads=1):
-    """Oracle (kind 'port') on the same workload; bounded number of sweeps.  threads=1 mirrors the reference's own execution
-    model (single Julia thread); threads>1 is the OpenMP run SURVEY.md 8(d) asks for as the stronger bar."""
+def host_cores():
+    """Threads this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows every core of the host
+    in the mask but grants a share of them) and by 16, the documented share of a one-GPU box."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(model, Y, logT, X, st, sweeps, threads=1, budget_s=30.0):
+    """Oracle (kind 'port') on the same workload.  threads=1 mirrors the reference's own execution model (single Julia thread);
+    threads>1 is the OpenMP run SURVEY.md 8(d) asks for as the stronger bar.  Bounded twice: at most `sweeps` sweeps and at most
+    ~budget_s seconds (checked after every sweep).  Returns (seconds per sweep, sweeps timed)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity_util as pu
     pu.oracle().orc_set_threads(int(threads))
-    op = pu.OracleProblem(model, Y, logT, X, st, qRt=0.85, cov2one=(model not in ("latentqr", "latent")))
-    op.run(1)                       # warm-up sweep (page in, first omega)
-    t0 = time.perf_counter()
-    op.run(sweeps)
-    dt = time.perf_counter() - t0
-    return dt / sweeps
+    try:
+        op = pu.OracleProblem(model, Y, logT, X, st, qRt=0.85, cov2one=(model not in ("latentqr", "latent")))
+        t0 = time.perf_counter()
+        op.run(1)                       # warm-up sweep (page in, first omega)
+        first = time.perf_counter() - t0
+        if first > budget_s:
+            return first, 1
+        n, t0 = 0, time.perf_counter()
+        while n < sweeps and time.perf_counter() - t0 < budget_s:
+            op.run(1)
+            n += 1
+        return (time.perf_counter() - t0) / max(n, 1), n
+    finally:
+        pu.oracle().orc_set_threads(1)
 
 
 def traffic_bytes(model, N, J, args):
@@ -97,6 +120,15 @@ def traffic_bytes(model, N, J, args):
     key = f"{model}:{N}x{J}:{args.precision}"
     e = t.get(key)
     return None if e is None else e.get("traffic_bytes_per_launch")
+
+
+def valu_profile(model, N, J, args):
+    """VALU-side counters of the same offline profile (profiles/traffic.json), or None: the kernel's real limiter."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{model}:{N}x{J}:{args.precision}")
+        return None if e is None else e.get("valu")
+    except Exception:
+        return None
 
 
 def main():
@@ -198,21 +230,21 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic_bytes(model, N, J, args), "kernel": "pass_kernel (one launch per sweep: tiny step + fused row pass; CrossQr: one of its two row passes)",
                                "frac_of_achievable": ach / 6300.0, "achievable_peak": 6300.0, "launch_us": per_launch_s * 1e6, "event_overhead_us": tm["event_overhead_ms"] * 1e3,
-                               "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"])}
+                               "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"]),
+                               "valu": valu_profile(model, N, J, args)}
         ncpu = args.cpu_sweeps
         if ncpu != 0:
             if ncpu < 0:
                 ncpu = max(2, int(round(15.0 / (cells * 2.6e-7))))      # ~0.26 us per cell-update on one host core
-            sec = cpu_baseline(model, Y, logT, X, st, ncpu)
+            sec, nrun = cpu_baseline(model, Y, logT, X, st, ncpu, budget_s=25.0)
             out["cpu_baseline"] = {"value": cells / sec, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-                                   "sample": f"{ncpu} sweeps of the same workload after 1 warm-up sweep; oracle/erm_oracle.c (fp64, "
+                                   "sample": f"{nrun} sweeps of the same workload after 1 warm-up sweep; oracle/erm_oracle.c (fp64, "
                                              f"reference's un-fused schedule); proxy for Julia sample! (Julia unavailable)",
                                    "s_per_sweep": sec}
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-            ncores = len(os.sched_getaffinity(0))
+            ncores = host_cores()
             if ncores > 1:
-                nmt = max(4, min(ncpu * ncores // 3, 40 * ncpu))       # ~5 s at perfect scaling
-                sec_mt = cpu_baseline(model, Y, logT, X, st, nmt, threads=ncores)
+                sec_mt, nmt = cpu_baseline(model, Y, logT, X, st, 8 * ncpu, threads=ncores, budget_s=8.0)
                 out["cpu_baseline_all_cores"] = {"value": cells / sec_mt, "unit": "cell-updates/s", "cores": ncores, "kind": "port",
                                                  "sample": f"{nmt} sweeps, same oracle with OpenMP over subjects/items ({ncores} threads)",
                                                  "s_per_sweep": sec_mt}

@@ -9,11 +9,11 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)      # gpurun merges runs: take the newest
+    return f[-1] if f else None
 
 
-def counters(path, kernel="pass_kernel"):
+def counters(path, kernel=", true>"):      # the fused sweep kernel pass_kernel<MODEL, real, 0, true> (the two non-fused launches are the prologue)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if kernel in r["Kernel_Name"]:
@@ -44,7 +44,16 @@ traffic = (fetch * corr + write) * 1024.0
 key = f"rtirt:{N}x{J}:{bench['dtype']}"
 tj_path = os.path.join(dst, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-tj[key] = {"traffic_bytes_per_launch": traffic, "fetch_size_kb_raw": fetch, "write_size_kb": write, "fetch_correction": corr,
+sq_path = os.path.join(dst, f"{tag}_sq_counters.json")
+valu = None
+if os.path.exists(sq_path):
+    sq = json.load(open(sq_path))
+    # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles; SQ_BUSY_CYCLES sums the 32 shader engines' busy cycles; 1024 SIMDs
+    if sq.get("SQ_BUSY_CYCLES") and sq.get("SQ_ACTIVE_INST_VALU"):
+        kernel_cycles = sq["SQ_BUSY_CYCLES"] / 32.0
+        valu = {"valu_busy_frac": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (1024.0 * kernel_cycles), "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"),
+                "valu_insts_per_cell_update": sq.get("SQ_INSTS_VALU", 0.0) * 64.0 / (N * J), "kernel_cycles": kernel_cycles}
+tj[key] = {"valu": valu, "traffic_bytes_per_launch": traffic, "fetch_size_kb_raw": fetch, "write_size_kb": write, "fetch_correction": corr,
            "calibration": f"row-sum phase alone (ERM_PASS_STOP=5) reads {known:.0f} KB and reports FETCH_SIZE {cal:.0f} KB", "source": f"profiles/{tag}_*"}
 json.dump(tj, open(tj_path, "w"), indent=1)
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
@@ -55,4 +64,7 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
     f.write(f"\nbench line of the same run: ms_per_step {bench['ms_per_step']:.4f}, roofline {json.dumps(bench.get('roofline'))}\n\n")
     f.write(f"pass_kernel HBM-side traffic per launch: FETCH_SIZE {fetch:.0f} KB x {corr:.2f} (calibrated) + WRITE_SIZE {write:.0f} KB = {traffic/1e6:.1f} MB "
             f"(algorithmic {13*N*J/1e6:.1f} MB)\n")
+    if valu:
+        f.write(f"\nVALU: {valu['valu_insts_per_launch']:.3g} wave-instructions per launch = {valu['valu_insts_per_cell_update']:.0f} per cell-update; VALU busy "
+                f"{100*valu['valu_busy_frac']:.0f} % of the kernel's cycles (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32))\n")
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())
