@@ -152,13 +152,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rehearse = os.environ.get("ERM_BENCH_REHEARSE") == "1"
+    coll_dev = "cpu" if rehearse else None
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:     # ERM_BENCH_REHEARSE=1: the N>1 code path on a ONE-GPU box -- every rank on cuda:0, collectives over gloo on the CPU
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ge.build_hip()
     pkg = ge.load_package()
@@ -189,7 +195,7 @@ def main():
     dt = time.perf_counter() - t0
     tm = eng.timing()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev or f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -203,7 +209,7 @@ def main():
                 setattr(P, k_dst, mean[k_src])
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        pkg.parallel.gather_posterior_summaries(P, eng.post_count, device=f"cuda:{local_rank}")
+        pkg.parallel.gather_posterior_summaries(P, eng.post_count, device=None if rehearse else f"cuda:{local_rank}")
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
@@ -233,7 +239,7 @@ def main():
                                "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"]),
                                "valu": valu_profile(model, N, J, args)}
         ncpu = args.cpu_sweeps
-        if ncpu != 0:
+        if ncpu != 0 and world == 1:          # the CPU baseline is reported at N=1 only
             if ncpu < 0:
                 ncpu = max(2, int(round(15.0 / (cells * 2.6e-7))))      # ~0.26 us per cell-update on one host core
             sec, nrun = cpu_baseline(model, Y, logT, X, st, ncpu, budget_s=25.0)
