@@ -4,7 +4,7 @@ Export list mirrors the part of /root/reference/src/ExtendedRtIrtModeling.jl:33-
 """
 from .base import InputData, InputData4R, InputPara, OutputDic, SimConditions, setCond
 from .gibbs import (GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCross, GibbsRtIrtCrossQr, GibbsRtIrtLatent, GibbsRtIrtLatentQr, GibbsRtIrtNull,
-                    GibbsRtIrtQuantile, coef, getDic,
+                    GibbsRtIrtQuantile, checkConvergence, coef, ess_rhat, getDic,
                     getLogLikelihood, precis, sample, sample_b)
 from .simtools import (getBias, getRmse, setDataMlIrt, setDataRtIrt, setDataRtIrtCross, setDataRtIrtLatent,
                        setTrueParaMlIrt, setTrueParaRtIrt, setTrueParaRtIrtCross, setTrueParaRtIrtLatent)
@@ -14,6 +14,6 @@ __all__ = [
     "setCond", "SimConditions", "InputData", "InputData4R", "InputPara", "OutputDic",
     "setDataMlIrt", "setDataRtIrt", "setDataRtIrtCross", "setDataRtIrtLatent",
     "setTrueParaMlIrt", "setTrueParaRtIrt", "setTrueParaRtIrtCross", "setTrueParaRtIrtLatent",
-    "getBias", "getRmse", "getDic", "getLogLikelihood", "sample_b", "sample",
+    "getBias", "getRmse", "getDic", "checkConvergence", "ess_rhat", "getLogLikelihood", "sample_b", "sample",
     "GibbsMlIrt", "GibbsRtIrt", "GibbsRtIrtCrossQr", "GibbsRtIrtLatentQr", "GibbsRtIrtQuantile", "GibbsRtIrtNull", "GibbsRtIrtCross", "GibbsRtIrtLatent", "coef", "precis",
 ]

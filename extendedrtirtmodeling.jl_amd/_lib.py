@@ -21,7 +21,7 @@ TRACE_RA, TRACE_RT, TRACE_QR, TRACE_LOGLIKE = 0, 1, 2, 3
 EXPORTS = [
     "erm_create", "erm_destroy", "erm_set_data", "erm_set_state", "erm_get_state", "erm_run", "erm_rows_done",
     "erm_reset_trace", "erm_trace_width", "erm_get_trace", "erm_item_trace_width", "erm_get_item_trace", "erm_get_mean",
-    "erm_post_count", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample",
+    "erm_post_count", "erm_get_diagnostics", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample",
 ]
 
 
@@ -86,6 +86,7 @@ def load():
     lib.erm_get_mean.argtypes = [H, C.POINTER(erm_state)]
     lib.erm_post_count.argtypes = [H]
     lib.erm_post_count.restype = C.c_int64
+    lib.erm_get_diagnostics.argtypes = [H, C.c_int, C.c_void_p, C.c_void_p]
     lib.erm_get_timing.argtypes = [H, C.POINTER(erm_timing)]
     lib.erm_last_error.restype = C.c_char_p
     lib.erm_version.restype = C.c_char_p
@@ -204,6 +205,13 @@ class Engine:
         out = np.empty((self.cfg.n_iter, w, self.cfg.n_chain), dtype=np.float64, order="F")
         check(self._lib.erm_get_trace(self._h, which, out.ctypes.data))
         return out
+
+    def diagnostics(self, which: int):
+        """(ess, rhat) of every column of Post.ra / rt / qr, computed on the device from the resident traces."""
+        w = int(self._lib.erm_trace_width(self._h, which))
+        ess, rhat = np.empty(w), np.empty(w)
+        check(self._lib.erm_get_diagnostics(self._h, which, ess.ctypes.data, rhat.ctypes.data))
+        return ess, rhat
 
     def item_trace(self):
         w = int(self._lib.erm_item_trace_width(self._h))

@@ -1204,6 +1204,64 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Convergence diagnostics on the device-resident traces (the reference pulls Post.ra/rt/qr through MCMCChains'
+// ess_rhat in checkConvergence, src/SimTools.jl:419-443): split-R-hat and the effective sample size by Geyer's initial monotone
+// sequence over the split chains (Gelman et al., BDA3 sec. 11.4-11.5; the non-rank-normalised estimator), one thread per parameter.
+//   draws: trace row (m * nChain + l), m >= nBurnin; each chain l is split into its first and last n = floor((nIter - nBurnin)/2)
+//   draws  => M = 2 nChain sequences.  W = mean of the sequences' variances (n-1 denominator), B/n = variance of their means,
+//   var+ = (n-1)/n W + B/n, rhat = sqrt(var+ / W), rho_t = 1 - (W - mean_c acov_c(t)) / var+ with acov_c(t) = 1/n sum_i (x_i - mu_c)
+//   (x_{i+t} - mu_c); P_k = rho_{2k} + rho_{2k+1} summed while positive and made non-increasing; ess = M n / (-1 + 2 sum_k P_k).
+// A parameter that never moves (beta[1] = 0, Sigma_p[1,1] = 1 ...) has W = 0 and gets NaN, as MCMCChains reports it.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int DIAG_MAXSEQ = 32;
+template <typename T>
+__global__ void diag_kernel(const T* tr, long long ncol, long long ld, int nIter, int nChain, int nBurnin, double* ess, double* rhat)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncol) return;
+    const int Tn = nIter - nBurnin, n = Tn / 2, M = 2 * nChain;
+    auto at = [&](int c, int i) -> double {                      // draw i of split sequence c
+        const int l = c >> 1, m0 = nBurnin + ((c & 1) ? Tn - n : 0);
+        return (double)tr[((long long)(m0 + i) * nChain + l) * ld + k];
+    };
+    double mu[DIAG_MAXSEQ];
+    double W = 0.0, mbar = 0.0;
+    for (int c = 0; c < M; ++c) {
+        double s1 = 0.0;
+        for (int i = 0; i < n; ++i) s1 += at(c, i);
+        mu[c] = s1 / n; mbar += mu[c];
+        double s2 = 0.0;
+        for (int i = 0; i < n; ++i) { const double d = at(c, i) - mu[c]; s2 += d * d; }
+        W += s2 / (n - 1);
+    }
+    W /= M; mbar /= M;
+    double Bn = 0.0;
+    for (int c = 0; c < M; ++c) Bn += (mu[c] - mbar) * (mu[c] - mbar);
+    Bn /= (M - 1);
+    const double varp = W * (n - 1) / n + Bn;
+    if (!(W > 0.0)) { ess[k] = __builtin_nan(""); rhat[k] = __builtin_nan(""); return; }
+    rhat[k] = sqrt(varp / W);
+    auto rho = [&](int t) -> double {
+        double a = 0.0;
+        for (int c = 0; c < M; ++c) {
+            double s = 0.0;
+            for (int i = 0; i + t < n; ++i) s += (at(c, i) - mu[c]) * (at(c, i + t) - mu[c]);
+            a += s / n;
+        }
+        return 1.0 - (W - a / M) / varp;
+    };
+    double sum = 0.0, prev = 1e300;
+    for (int t = 0; t + 1 < n; t += 2) {
+        double P = (t == 0 ? 1.0 - (W - W * (n - 1) / n) / varp : rho(t)) + rho(t + 1);
+        if (!(P > 0.0)) break;
+        if (P > prev) P = prev;
+        prev = P;
+        sum += P;
+    }
+    ess[k] = (double)M * n / (-1.0 + 2.0 * sum);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // unit kernels for parity tests of the device samplers against the oracle
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename real>

@@ -52,6 +52,7 @@ struct EngineBase {
     virtual int get_trace(int, double*) = 0;
     virtual int get_item_trace(double*) = 0;
     virtual int get_mean(erm_state*) = 0;
+    virtual int get_diagnostics(int, double*, double*) = 0;
     virtual int reset_trace() = 0;
     int64_t rows_done = 0;
     int64_t post_rows = 0;
@@ -743,6 +744,74 @@ template <typename real> struct Engine : EngineBase {
         return 0;
     }
 
+    // ess / rhat of every column of Post.ra / rt / qr, computed on the device from the resident traces (diag_kernel)
+    int get_diagnostics(int which, double* ess, double* rhat) override {
+        HIPCHK(hipSetDevice(cfg.device));
+        const int64_t wd = trace_width(which);
+        if (which == ERM_TRACE_LOGLIKE || wd <= 0) return fail(ERM_ERR_ARG, "diagnostics exist for the ra / rt / qr traces");
+        if (rows_done != rows_cap) return fail(ERM_ERR_STATE, "trace incomplete: run n_iter*n_chain sweeps first");
+        if (cfg.trace_mode != ERM_TRACE_FULL) return fail(ERM_ERR_NOTRACE, "subject-level traces need trace_mode = ERM_TRACE_FULL");
+        const int Tn = cfg.n_iter - cfg.n_burnin;
+        if (Tn / 2 < 4) return fail(ERM_ERR_ARG, "too few post-burn-in iterations for split-chain diagnostics (need >= 8)");
+        if (2 * cfg.n_chain > DIAG_MAXSEQ) return fail(ERM_ERR_ARG, "too many chains for the diagnostics kernel");
+        HIPCHK(hipStreamSynchronize(stream));
+        DevBuf dE, dR;
+        if (int rc = dE.alloc((size_t)wd * sizeof(double))) return rc;
+        if (int rc = dR.alloc((size_t)wd * sizeof(double))) return rc;
+        auto launch_real = [&](const DevBuf& tr, int64_t ncol, int64_t off) -> int {
+            if (!tr.p) return fail(ERM_ERR_NOTRACE, "this trace was not recorded");
+            hipLaunchKernelGGL((diag_kernel<real>), dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, stream, tr.as<real>(), (long long)ncol, (long long)ncol,
+                               cfg.n_iter, cfg.n_chain, cfg.n_burnin, dE.as<double>() + off, dR.as<double>() + off);
+            return 0;
+        };
+        auto launch_item = [&](int64_t col0, int64_t ncol, int64_t off) -> int {
+            hipLaunchKernelGGL((diag_kernel<double>), dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, stream, dTrItem.as<double>() + col0, (long long)ncol,
+                               (long long)item_trace_width(), cfg.n_iter, cfg.n_chain, cfg.n_burnin, dE.as<double>() + off, dR.as<double>() + off);
+            return 0;
+        };
+        const int q = nq();
+        if (which == ERM_TRACE_RA) {            // [theta; a; b]
+            if (int rc = launch_real(dTrTheta, N, 0)) return rc;
+            if (int rc = launch_item(0, 2 * J, N)) return rc;
+        } else if (which == ERM_TRACE_RT) {     // [zeta; lambda; sig2t]
+            if (int rc = launch_real(dTrZeta, N, 0)) return rc;
+            if (int rc = launch_item(2 * J, 2 * J, N)) return rc;
+        } else if (cfg.model == ERM_MODEL_NULL) {   // [vec(beta) = 0; vec(Sigp)]: the zeros are constant -> NaN
+            const int nb = 2 * ((int)F + 1);
+            std::vector<double> nanv(nb, std::nan(""));
+            HIPCHK(hipMemcpyAsync(dE.p, nanv.data(), nb * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(dR.p, nanv.data(), nb * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (int rc = launch_item(4 * J + 2, 4, nb)) return rc;
+        } else {
+            if (int rc = launch_item(4 * J, q, 0)) return rc;
+            if (cfg.model == ERM_MODEL_LATENTQR) { if (int rc = launch_real(dTrNu, N, q)) return rc; }
+            if (cfg.model == ERM_MODEL_CROSSQR) {
+                // vec(nu) in Post.qr is column-major N x J; the device trace is row-major: diagnose in device order, permute on the host
+                if (!dTrNu.p) return fail(ERM_ERR_NOTRACE, "the per-sweep nu trace was not recorded (ERM_NU_TRACE_MAX_GB)");
+                DevBuf e2, r2;
+                if (int rc = e2.alloc((size_t)N * J * sizeof(double))) return rc;
+                if (int rc = r2.alloc((size_t)N * J * sizeof(double))) return rc;
+                hipLaunchKernelGGL((diag_kernel<real>), dim3((unsigned)(((int64_t)N * J + 255) / 256)), dim3(256), 0, stream, dTrNu.as<real>(), (long long)N * J,
+                                   (long long)N * J, cfg.n_iter, cfg.n_chain, cfg.n_burnin, e2.as<double>(), r2.as<double>());
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(stream));
+                std::vector<double> he((size_t)N * J), hr((size_t)N * J);
+                HIPCHK(hipMemcpy(he.data(), e2.p, he.size() * sizeof(double), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(hr.data(), r2.p, hr.size() * sizeof(double), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(ess, dE.p, (size_t)q * sizeof(double), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(rhat, dR.p, (size_t)q * sizeof(double), hipMemcpyDeviceToHost));
+                for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) { ess[q + i + N * j] = he[(size_t)i * J + j]; rhat[q + i + N * j] = hr[(size_t)i * J + j]; }
+                return 0;
+            }
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipMemcpy(ess, dE.p, (size_t)wd * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(rhat, dR.p, (size_t)wd * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    }
+
     int get_mean(erm_state* out) override {
         if (!out) return fail(ERM_ERR_ARG, "state is NULL");
         HIPCHK(hipSetDevice(cfg.device));
@@ -817,6 +886,7 @@ int64_t erm_item_trace_width(erm_handle h) { return h ? h->e->item_trace_width()
 int erm_get_item_trace(erm_handle h, double* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_item_trace(out); }
 int erm_get_mean(erm_handle h, erm_state* out) { CHK_H; return h->e->get_mean(out); }
 int64_t erm_post_count(erm_handle h) { return h ? h->e->post_rows : -1; }
+int erm_get_diagnostics(erm_handle h, int which, double* ess, double* rhat) { CHK_H; if (!ess || !rhat) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_diagnostics(which, ess, rhat); }
 int erm_get_timing(erm_handle h, erm_timing* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); *out = h->e->timing; return 0; }
 const char* erm_last_error(void) { return g_err.c_str(); }
 const char* erm_version(void) { return "ertirt-amd 0.1.0 (gfx950)"; }

@@ -336,6 +336,66 @@ def getDic(MCMC: _GibbsBase) -> OutputDic:
     return OutputDic(pD=pD, DIC=Dbar + pD)
 
 
+def ess_rhat(x: np.ndarray):
+    """Split-R-hat and effective sample size (Geyer's initial monotone sequence over the split chains; BDA3 sec. 11.4-11.5, the
+    non-rank-normalised estimator) of draws x[(iteration, chain)] -- the host twin of the device kernel `diag_kernel`, used by its
+    tests and for traces that are not resident on the device."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[:, None]
+    T, C = x.shape
+    n = T // 2
+    seq = np.stack([x[:n, l] if h == 0 else x[T - n:, l] for l in range(C) for h in (0, 1)])      # (M, n)
+    M = seq.shape[0]
+    mu = seq.mean(axis=1)
+    d = seq - mu[:, None]
+    W = np.mean(np.sum(d * d, axis=1) / (n - 1))
+    Bn = np.sum((mu - mu.mean()) ** 2) / (M - 1)
+    varp = W * (n - 1) / n + Bn
+    if not W > 0:
+        return float("nan"), float("nan")
+
+    def rho(t):
+        return 1.0 - (W - np.mean(np.sum(d[:, :n - t] * d[:, t:], axis=1) / n)) / varp
+
+    total, prev, t = 0.0, np.inf, 0
+    while t + 1 < n:
+        P = rho(t) + rho(t + 1)
+        if not P > 0:
+            break
+        P = min(P, prev)
+        prev = P
+        total += P
+        t += 2
+    return M * n / (-1.0 + 2.0 * total), float(np.sqrt(varp / W))
+
+
+def checkConvergence(MCMC: _GibbsBase) -> dict:
+    """src/SimTools.jl:419-443: share of the ra / rt / qr columns with ESS > 400 and R-hat < 1.1 after burn-in.  The reference runs
+    MCMCChains' `ess_rhat` on the host; here both statistics come from the device-resident traces (erm_get_diagnostics; split-R-hat and
+    Geyer's initial-monotone-sequence ESS, not rank-normalised -- MCMCChains' version is not pinned by the reference).  Columns that
+    never move (NaN) are left out of the denominators, as the reference does for qr."""
+    eng = MCMC._engine
+    if eng is None:
+        raise ValueError("run sample! first")
+    ess_n = rhat_n = ess_ok = rhat_ok = 0
+    out = {}
+    for name, which in (("ra", _lib.TRACE_RA), ("rt", _lib.TRACE_RT), ("qr", _lib.TRACE_QR)):
+        if which == _lib.TRACE_RT and MCMC._model == _lib.MODEL_MLIRT:
+            continue
+        try:
+            ess, rhat = eng.diagnostics(which)
+        except _lib.ErmError:
+            if which != _lib.TRACE_QR:
+                raise
+            continue                                    # CrossQr without a resident nu trace
+        out[name] = (ess, rhat)
+        ess_n += int(np.sum(~np.isnan(ess))); rhat_n += int(np.sum(~np.isnan(rhat)))
+        ess_ok += int(np.sum(ess > 400)); rhat_ok += int(np.sum(rhat < 1.1))
+    return dict(ess=100.0 * ess_ok / max(ess_n, 1), rhat=100.0 * rhat_ok / max(rhat_n, 1), essN=f"{ess_ok} / {ess_n}",
+                rhatN=f"{rhat_ok} / {rhat_n}", detail=out)
+
+
 def coef(MCMC: _GibbsBase) -> dict:
     """Posterior-mean tables of `coef` (src/GibbsRtIrt.pl.jl:479-538) as plain arrays (pretty-printing is out of scope)."""
     C, M = MCMC.Cond, MCMC.Post.mean

@@ -112,6 +112,12 @@ int erm_get_item_trace(erm_handle h, double* out);
 int erm_get_mean(erm_handle h, erm_state* out);
 int64_t erm_post_count(erm_handle h);   /* number of rows that entered the means */
 
+/* checkConvergence's inputs (src/SimTools.jl:419-443, MCMCChains' ess_rhat on Post.ra / rt / qr after burn-in), computed on the device
+ * from the resident traces: ess[k], rhat[k] for every column k of trace `which` (width erm_trace_width); split-R-hat and the effective
+ * sample size by Geyer's initial monotone sequence over the 2*nChain split chains (the non-rank-normalised estimator); NaN for a column
+ * that never moves.  Needs ERM_TRACE_FULL and a completed run. */
+int erm_get_diagnostics(erm_handle h, int which, double* ess, double* rhat);
+
 int erm_get_timing(erm_handle h, erm_timing* out);
 const char* erm_last_error(void);
 const char* erm_version(void);

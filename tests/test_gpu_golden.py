@@ -90,3 +90,31 @@ def test_crossqr_post_qr_carries_rho_sigp_and_vec_nu():
     assert np.all(P.qr[:, J + 4:, 0] > 0)
     assert np.allclose(np.asarray(P.mean.nu).reshape(-1, order="F"), P.qr[3:, J + 4:, 0].mean(axis=0), rtol=1e-12)
     assert np.allclose(P.mean.rho, P.qr[3:, :J, 0].mean(axis=0))
+
+
+@pytest.mark.parametrize("name,model,nchain", [("GibbsRtIrt", "rtirt", 1), ("GibbsRtIrt", "rtirt", 2), ("GibbsRtIrtLatentQr", "latentqr", 1),
+                                               ("GibbsRtIrtCrossQr", "crossqr", 1), ("GibbsMlIrt", "mlirt", 2)])
+def test_device_diagnostics_match_the_host_estimator(name, model, nchain):
+    """erm_get_diagnostics (ESS and split-R-hat of every Post.ra / rt / qr column from the device-resident traces) against the numpy
+    twin applied to the traces pulled to the host; checkConvergence's summary (src/SimTools.jl:419-443)."""
+    pkg = pu.ge.load_package()
+    z, Y, logT, X, init = load_golden(model)
+    N, J = Y.shape
+    Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=0 if model == "crossqr" else 3, nIter=120, nChain=nchain, qRt=0.85)
+    D = pkg.InputData(Y=Y, T=np.exp(logT) if logT is not None else np.ones_like(Y, dtype=float), X=X if X is not None else np.zeros((N, 0)))
+    M = getattr(pkg, name)(Cond, Data=D, precision="f32")
+    pkg.sample_b(M)
+    conv = pkg.checkConvergence(M)
+    nb = Cond.nBurnin
+    for tr_name in conv["detail"]:
+        ess, rhat = conv["detail"][tr_name]
+        tr = getattr(M.Post, tr_name)
+        assert ess.shape == (tr.shape[1],)
+        for k in list(range(0, tr.shape[1], max(1, tr.shape[1] // 40))) + [tr.shape[1] - 1]:
+            e, r = pkg.ess_rhat(tr[nb:, k, :])
+            if np.isnan(e):
+                assert np.isnan(ess[k]) and np.isnan(rhat[k]), (tr_name, k)
+            else:
+                assert abs(ess[k] - e) <= 1e-6 * abs(e) and abs(rhat[k] - r) <= 1e-9, (tr_name, k, ess[k], e)
+    assert 0 <= conv["ess"] <= 100 and 0 <= conv["rhat"] <= 100 and " / " in conv["essN"]
+    assert conv["rhat"] > 50          # most subject-level parameters mix well within 60 post-burn-in iterations per chain

@@ -101,3 +101,23 @@ def test_simtools_generators_shapes_and_ranges():
     D = pkg.setDataMlIrt(Cond, tp, seed=2)
     assert set(np.unique(D.X[:, 0])) <= {0.0, 1.0}
     assert pkg.getRmse([1, 2], [1, 4]) == pytest.approx(np.sqrt(2)) and pkg.getBias([1, 2], [1, 4]) == -1
+
+
+def test_ess_rhat_estimator_on_known_processes():
+    """Host twin of the device diagnostics kernel: iid draws have ESS ~ number of draws and R-hat ~ 1; an AR(1) process with
+    coefficient phi has ESS ~ n (1 - phi) / (1 + phi); chains with different means have R-hat >> 1; a constant column is NaN."""
+    g = np.random.default_rng(0)
+    T, C = 4000, 2
+    ess, rhat = pkg.ess_rhat(g.standard_normal((T, C)))
+    assert 0.8 * T * C < ess < 1.25 * T * C and abs(rhat - 1) < 0.01
+    phi = 0.8
+    x = np.zeros((T, C))
+    e = g.standard_normal((T, C))
+    for t in range(1, T):
+        x[t] = phi * x[t - 1] + e[t]
+    ess, rhat = pkg.ess_rhat(x)
+    want = T * C * (1 - phi) / (1 + phi)
+    assert 0.7 * want < ess < 1.4 * want and rhat < 1.02
+    ess, rhat = pkg.ess_rhat(g.standard_normal((T, C)) + np.array([0.0, 3.0]))
+    assert rhat > 1.5 and ess < 20
+    assert all(np.isnan(v) for v in pkg.ess_rhat(np.ones((T, C))))
