@@ -631,8 +631,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     // FUSED only: LDS scratch of the tiny step, appended to the pass layout
     const int NS0 = NSTAT * J + NG;
     double* st0 = reinterpret_cast<double*>(sh_val + (((size_t)A.rows_per_block * NV + 1) & ~(size_t)1));   // 8-byte aligned
-    double* part = st0 + NS0;
-    double* work = part + NS0;
+    double* part = st0 + NS0;                                   // J doubles (1/sig2t_j)
+    double* work = part + J;
     double* sh_x = work + TINY_WORK;
     double* lp = sh_x + 2 * PMAX * PMAX;
     double* lcst = lp + par_size(J);                            // K0, column means, csq, muLam, sdLam (3J + 2)
@@ -1158,7 +1158,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     stamp(13);
 }
 
-constexpr int tiny_lds_doubles(int NS0, int NS1, int J) { return NS0 + NS1 + 4 * (NS0 > NS1 ? NS0 : NS1) + TINY_WORK + 2 * PMAX * PMAX + par_size(J); }
+constexpr int tiny_lds_doubles(int NS0, int NS1, int J) { return NS0 + NS1 + J + TINY_WORK + 2 * PMAX * PMAX + par_size(J); }
 
 template <int MODEL, int STEP>
 __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
@@ -1174,8 +1174,8 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* st0 = reinterpret_cast<double*>(smem);          // NS0 reduced statistics of slab0
     double* st1 = st0 + NS0;                                // NS1 reduced statistics of slab1
-    double* part = st1 + NS1;                               // 4 * max(NS0, NS1) partial sums
-    double* work = part + 4 * (NS0 > NS1 ? NS0 : NS1);      // TINY_WORK scratch
+    double* part = st1 + NS1;                               // J doubles (1/sig2t_j)
+    double* work = part + J;                                // TINY_WORK scratch
     double* sh_x = work + TINY_WORK;                        // x'x and its inverse (2 * PMAX * PMAX), staged once
     double* lp = sh_x + 2 * PMAX * PMAX;                    // the parameter block, updated in place and written back at the end
     const int tid = threadIdx.x;

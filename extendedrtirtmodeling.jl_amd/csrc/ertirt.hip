@@ -109,7 +109,8 @@ template <typename real> struct Engine : EngineBase {
     DevBuf dDbgTs;                                   // ERM_TIMELINE diagnostics
     int cur = 0;
     int n_groups = 1;
-    bool fused() const { return !m_cq(); }        // single-pass models run the tiny step inside the row-pass kernel
+    bool fuse_ok = true;                              // false when the fused kernel's LDS layout cannot fit (very long tests): two kernels per sweep then
+    bool fused() const { return !m_cq() && fuse_ok; }  // single-pass models run the tiny step inside the row-pass kernel
     DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
 
     ~Engine() override {
@@ -196,6 +197,15 @@ template <typename real> struct Engine : EngineBase {
         block_threads = cfg.block_threads > 0 ? cfg.block_threads : max_threads;
         if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= 1024 (fp32) / 512 (fp64)");
         const int R = 64 / W;
+        // the per-wave item accumulators (nWaves x NSTAT x nItem doubles) dominate LDS for long tests: fewer waves per workgroup then
+        if (cfg.block_threads == 0) {
+            while (block_threads > 64) {
+                const size_t acc = (size_t)(block_threads / 64) * nstat(0) * J * sizeof(double);
+                const size_t fixed = (size_t)NITEMARR * J * sizeof(real) + (size_t)(stat_sizes(0) + 5 * J + 2 * J + TINY_WORK + 2 * PMAX * PMAX + 64) * sizeof(double);
+                if (acc + fixed <= 120 * 1024) break;
+                block_threads /= 2;
+            }
+        }
         const int nWaves = block_threads / 64;
         const int64_t need = (N + nWaves - 1) / nWaves;         // at least one subject per wave
         const int per_cu = std::max(1, 16 / nWaves);
@@ -213,6 +223,11 @@ template <typename real> struct Engine : EngineBase {
             const size_t need_lds = std::max(std::max(lds_pass[0], lds_pass[1]), fused() ? fused_lds() : (size_t)0);
             if (need_lds <= 158 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
             grid_blocks *= 2;
+        }
+        if (fused() && fused_lds() > 160 * 1024) {       // the tiny step's scratch does not fit next to the pass layout: keep the two-kernel schedule
+            fuse_ok = false;
+            rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
+            for (int ph = 0; ph < 2; ++ph) lds_pass[ph] = pass_lds(ph, nWaves);
         }
         if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads or raise grid_blocks");
 
@@ -285,10 +300,7 @@ template <typename real> struct Engine : EngineBase {
     }
     // the fused kernel appends the tiny step's scratch (statistics, partials, structural scratch, x'x, parameter block) to the pass layout
     size_t fused_lds() const { return lds_pass[0] + 8 + (size_t)(2 * ns[0] + TINY_WORK + 2 * PMAX * PMAX + par_size(J) + 3 * J + 2) * sizeof(double); }
-    size_t tiny_lds() const {
-        const int mx = std::max(ns[0], ns[1]);
-        return (size_t)(ns[0] + (m_cq() ? ns[1] : 0) + 4 * mx + TINY_WORK + 2 * PMAX * PMAX + par_size(J)) * sizeof(double);
-    }
+    size_t tiny_lds() const { return (size_t)tiny_lds_doubles(ns[0], m_cq() ? ns[1] : 0, J) * sizeof(double); }
     int configure_kernels() {
         const int tl = (int)tiny_lds();
         if (tl > 160 * 1024) return fail(ERM_ERR_ARG, "tiny-step LDS footprint too large");
@@ -297,8 +309,7 @@ template <typename real> struct Engine : EngineBase {
             if (int rc = set_lds_attr<M, 0, false>(lds_pass[0])) return rc;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<M, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
             if constexpr (!fam_cq(M)) {
-                if (fused_lds() > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads or raise grid_blocks");
-                if (int rc = set_lds_attr<M, 0, true>(fused_lds())) return rc;
+                if (fused()) { if (int rc = set_lds_attr<M, 0, true>(fused_lds())) return rc; }
             }
             if constexpr (fam_cq(M)) {
                 if (int rc = set_lds_attr<M, 1, false>(lds_pass[1])) return rc;
@@ -381,7 +392,7 @@ template <typename real> struct Engine : EngineBase {
     static constexpr int PROFILE_STRIDE = 8;
     hipGraphExec_t graph_exec = nullptr;
     template <int MODEL> int enqueue_sweep(bool first, bool timed) {
-        if constexpr (!fam_cq(MODEL)) return launch_fused<MODEL>(first, timed);
+        if constexpr (!fam_cq(MODEL)) { if (fused()) return launch_fused<MODEL>(first, timed); }
         if (int rc = launch_tiny<MODEL, 0>(0, first)) return rc;
         if (int rc = launch_pass<MODEL, 0>(1, timed)) return rc;
         if constexpr (fam_cq(MODEL)) {

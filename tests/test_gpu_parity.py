@@ -202,3 +202,29 @@ def test_summary_mode_matches_full_mode():
         assert np.array_equal(mf[k], ms[k])
     with pytest.raises(Exception):
         summ["engine"].trace(0)
+
+
+@pytest.mark.parametrize("model,N,J,F", [("rtirt", 64, 896, 1), ("rtirt", 300, 5, 14), ("latentqr", 300, 5, 14), ("latent", 300, 5, 14),
+                                         ("mlirt", 300, 5, 14), ("rtirt", 2, 3, 0), ("crossqr", 3, 2, 0), ("latentqr", 5, 1, 1)])
+def test_f64_limits_of_the_engine(model, N, J, F):
+    """The documented limits (nItem <= 896, nFeat <= 14) and degenerate sizes (a handful of subjects / one item)."""
+    res = pu.run_pair(model, N=N, J=J, nsweeps=3, F=F, precision="f64")
+    assert pu.max_rel_err(res, floor=1e-5) < 1e-7
+
+
+def test_two_engines_in_one_process_do_not_interfere():
+    """Distinct handles are independent (include/ertirt.h): interleaved runs of two engines equal their separate runs."""
+    Y, logT, X, init, _ = pu.make_problem("rtirt", 400, 8)
+    ref = pu.run_device("rtirt", Y, logT, X, init, 6, precision="f64")["ra"]
+    L = pu.ge.load_package()._lib
+    engs = []
+    for _ in range(2):
+        e = L.Engine(model=1, n_item=8, n_subj=400, n_feat=3, n_iter=6, n_chain=1, n_burnin=3, cov2one=1, q_rt=0.85, seed=1234, precision=1, trace_mode=1)
+        e.set_data(Y, logT, X)
+        e.set_state(**init)
+        engs.append(e)
+    for k in range(3):
+        for e in engs:
+            e.run(2)
+    for e in engs:
+        assert np.array_equal(e.trace(L.TRACE_RA), ref)
