@@ -57,9 +57,11 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    // one three-input XOR per word (v_bitop3_b32, truth table 0x96) instead of the two two-input ones the compiler emits
+    uint32_t n0, n2;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"((uint32_t)(p1 >> 32)), "v"(c1), "s"(k0));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"((uint32_t)(p0 >> 32)), "v"(c3), "s"(k1));
     const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
     const uint32_t n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
@@ -186,7 +188,8 @@ __device__ __forceinline__ double ndtri(double p)
 
 template <typename real> __device__ __forceinline__ real word_to_unif(uint32_t w);
 template <> __device__ __forceinline__ double word_to_unif<double>(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
-template <> __device__ __forceinline__ float word_to_unif<float>(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+// ((w >> 9) + 1/2) 2^-23, formed exactly without an int->float conversion: 1.m - (1 - 2^-24), both operands and the result representable
+template <> __device__ __forceinline__ float word_to_unif<float>(uint32_t w) { return __uint_as_float((w >> 9) | 0x3F800000u) - 0.99999994f; }
 
 // ---- Polya-Gamma PG(1, c) -------------------------------------------------------------------
 // Single-level rejection sampler for J*(1, z): one attempt = one Philox block (u0..u3), no inner loop.  Envelope pieces:
