@@ -6,13 +6,15 @@ from .base import InputData, InputData4R, InputPara, OutputDic, SimConditions, s
 from .gibbs import (GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCross, GibbsRtIrtCrossQr, GibbsRtIrtLatent, GibbsRtIrtLatentQr, GibbsRtIrtNull,
                     GibbsRtIrtQuantile, checkConvergence, coef, ess_rhat, getDic,
                     getLogLikelihood, precis, sample, sample_b)
-from .simtools import (getBias, getRmse, setDataMlIrt, setDataRtIrt, setDataRtIrtCross, setDataRtIrtLatent,
+from .simtools import (comparePara, getBias, getMetrics, getMetrics2, getRmse, runSimulation, setDataMlIrt, setDataRtIrt, setDataRtIrtCross,
+                       setDataRtIrtLatent, setDataRtIrtNull,
                        setTrueParaMlIrt, setTrueParaRtIrt, setTrueParaRtIrtCross, setTrueParaRtIrtLatent)
 from . import _lib, parallel
 
 __all__ = [
     "setCond", "SimConditions", "InputData", "InputData4R", "InputPara", "OutputDic",
-    "setDataMlIrt", "setDataRtIrt", "setDataRtIrtCross", "setDataRtIrtLatent",
+    "setDataMlIrt", "setDataRtIrt", "setDataRtIrtCross", "setDataRtIrtLatent", "setDataRtIrtNull", "runSimulation", "getMetrics", "getMetrics2",
+    "comparePara",
     "setTrueParaMlIrt", "setTrueParaRtIrt", "setTrueParaRtIrtCross", "setTrueParaRtIrtLatent",
     "getBias", "getRmse", "getDic", "checkConvergence", "ess_rhat", "getLogLikelihood", "sample_b", "sample",
     "GibbsMlIrt", "GibbsRtIrt", "GibbsRtIrtCrossQr", "GibbsRtIrtLatentQr", "GibbsRtIrtQuantile", "GibbsRtIrtNull", "GibbsRtIrtCross", "GibbsRtIrtLatent", "coef", "precis",

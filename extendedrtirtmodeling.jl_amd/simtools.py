@@ -149,3 +149,89 @@ def getRmse(a, b):
 def getBias(a, b):
     """src/SimTools.jl:43"""
     return float(np.mean(np.asarray(a) - np.asarray(b)))
+
+
+def setDataRtIrtNull(Cond: SimConditions, truePara: InputPara, *, seed=4321):
+    """src/SimTools.jl:117-144: (theta, zeta) ~ N2(0, Sigp), no covariates"""
+    g = _rng(seed)
+    L = np.linalg.cholesky(np.asarray(truePara.Sigp).reshape(2, 2))
+    subj = g.standard_normal((Cond.nSubj, 2)) @ L.T
+    truePara.theta, truePara.zeta = subj[:, 0], subj[:, 1]
+    Y = _bernoulli_logit(g, truePara.a[None, :] * (truePara.theta[:, None] - truePara.b[None, :]))
+    mut = truePara.lam[None, :] - truePara.zeta[:, None]
+    logT = _truncnorm(g, mut, np.sqrt(truePara.sig2t)[None, :], 0.0, np.inf, mut.shape)
+    return InputData(Y=Y, T=np.exp(logT))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The callers of sample! in a simulation study (src/SimTools.jl:389-443, 457-552).  Host-side bookkeeping around the GPU path.
+# ------------------------------------------------------------------------------------------------------------------
+_ALIASES = {"λ": "lam", "σ²t": "sig2t", "ρ": "rho", "β": "beta", "Σp": "Sigp", "θ": "theta", "ζ": "zeta", "ν": "nu"}
+
+
+def _field(obj, name):
+    return np.asarray(getattr(obj, _ALIASES.get(name, name)), dtype=np.float64)
+
+
+def runSimulation(Cond: SimConditions, truePara: InputPara, *, Para=("a", "b", "λ", "σ²t"), funcData=None, funcGibbs=None, typeName="norm",
+                  seed=4321, **gibbs_opts):
+    """src/SimTools.jl:457-495: Cond.nRep replications of  data <- funcData(Cond, truePara); MCMC <- funcGibbs(Cond; truePara, Data);
+    sample!(MCMC);  keeping Post.mean of the parameters in `Para`, the DIC and checkConvergence's summary of every replication.
+    funcData / funcGibbs are callables (the reference looks their names up in Main); defaults setDataRtIrt / GibbsRtIrt.
+    Returns {"True": {par: vec}, 1: {par: vec, "Dic": [dic], "Diag": {...}}, ..., nRep: {...}} like the reference's Dict."""
+    import inspect
+    from . import gibbs
+    funcData = funcData or setDataRtIrt
+    funcGibbs = funcGibbs or gibbs.GibbsRtIrt
+    Run = {"True": {p: _field(truePara, p).reshape(-1, order="F") for p in Para}}
+    takes_type = "type" in inspect.signature(funcData).parameters
+    for run in range(1, Cond.nRep + 1):
+        kw = dict(seed=np.random.SeedSequence([seed, run]))
+        if takes_type:
+            kw["type"] = typeName
+        Data = funcData(Cond, truePara, **kw)
+        MCMC = funcGibbs(Cond, truePara=truePara, Data=Data, seed=seed + run, **gibbs_opts)
+        try:
+            gibbs.sample_b(MCMC)
+            Post = {p: _field(MCMC.Post.mean, p).reshape(-1, order="F") for p in Para}
+            Post["Dic"] = [gibbs.getDic(MCMC).DIC]
+            Post["Diag"] = {k: v for k, v in gibbs.checkConvergence(MCMC).items() if k != "detail"} if MCMC.trace == "full" else None
+        finally:
+            MCMC.close()
+        Run[run] = Post
+    return Run
+
+
+def _stack(obj, par):
+    true = np.asarray(obj["True"][par], dtype=np.float64)
+    runs = [k for k in obj if k != "True"]
+    esti = np.column_stack([np.asarray(obj[k][par], dtype=np.float64) for k in runs])
+    if par in ("β", "beta") and esti.shape[0] == true.size + 1:
+        esti = esti[1:]                                   # the intercept row is not part of the truth (src/SimTools.jl:501-506)
+    return true, esti
+
+
+def getMetrics(obj, *, par="a"):
+    """src/SimTools.jl:500-523 over however many replications `obj` holds (the reference hard-codes 100)."""
+    true, esti = _stack(obj, par)
+    d = esti - true[:, None]
+    return dict(Bias=float(np.mean(d)), Rmse=float(np.sqrt(np.mean(d ** 2))),
+                Corr=float(np.mean([np.corrcoef(esti[:, k], true)[0, 1] for k in range(esti.shape[1])])))
+
+
+def getMetrics2(obj, *, par="a"):
+    """src/SimTools.jl:528-551"""
+    true, esti = _stack(obj, par)
+    d = esti - true[:, None]
+    return dict(relativeBias=float(np.mean(d / true[:, None])), normalizedRmse=float(np.sqrt(np.mean(d ** 2)) / (esti.max() - esti.min())),
+                Corr=float(np.mean([np.corrcoef(esti[:, k], true)[0, 1] for k in range(esti.shape[1])])))
+
+
+def comparePara(Mcmc, *, par="a", digits=3):
+    """src/SimTools.jl:389-413: the (Esti, True, |Diff|) table as an array (the reference prints it)."""
+    true = _field(Mcmc.truePara, par).reshape(-1, order="F")
+    esti = _field(Mcmc.Post.mean, par).reshape(-1, order="F")
+    if par in ("β", "beta") and esti.size != true.size:
+        nf = Mcmc.Cond.nFeat
+        esti = esti.reshape(nf + 1, -1, order="F")[1:].reshape(-1, order="F")
+    return np.round(np.column_stack([esti, true, np.abs(esti - true)]), digits)

@@ -118,3 +118,20 @@ def test_device_diagnostics_match_the_host_estimator(name, model, nchain):
                 assert abs(ess[k] - e) <= 1e-6 * abs(e) and abs(rhat[k] - r) <= 1e-9, (tr_name, k, ess[k], e)
     assert 0 <= conv["ess"] <= 100 and 0 <= conv["rhat"] <= 100 and " / " in conv["essN"]
     assert conv["rhat"] > 50          # most subject-level parameters mix well within 60 post-burn-in iterations per chain
+
+
+def test_run_simulation_like_the_reference():
+    """runSimulation (src/SimTools.jl:457-495): nRep data sets from one truth, sample! on each, Post.mean / DIC / convergence summary
+    per replication, then getMetrics over the replications."""
+    pkg = pu.ge.load_package()
+    Cond = pkg.setCond(nSubj=800, nItem=10, nFeat=2, nIter=300, nChain=1, nRep=3)
+    tp = pkg.setTrueParaRtIrt(Cond, seed=3)
+    Run = pkg.runSimulation(Cond, tp, Para=("a", "b", "λ", "σ²t"), funcData=pkg.setDataRtIrt, funcGibbs=pkg.GibbsRtIrt)
+    assert set(Run) == {"True", 1, 2, 3} and set(Run[1]) == {"a", "b", "λ", "σ²t", "Dic", "Diag"}
+    assert np.isfinite(Run[2]["Dic"][0]) and " / " in Run[3]["Diag"]["essN"]
+    assert not np.array_equal(Run[1]["a"], Run[2]["a"])                      # different data sets
+    m = pkg.getMetrics(Run, par="b")
+    assert m["Rmse"] < 0.2 and m["Corr"] > 0.9 and abs(m["Bias"]) < 0.1
+    null = pkg.runSimulation(pkg.setCond(nSubj=500, nItem=8, nFeat=0, nIter=200, nChain=1, nRep=1), tp.__class__(
+        a=tp.a[:8], b=tp.b[:8], lam=tp.lam[:8], sig2t=tp.sig2t[:8], Sigp=np.eye(2)), funcData=pkg.setDataRtIrtNull, funcGibbs=pkg.GibbsRtIrtNull)
+    assert pkg.getMetrics(null, par="a")["Rmse"] < 0.3

@@ -121,3 +121,13 @@ def test_ess_rhat_estimator_on_known_processes():
     ess, rhat = pkg.ess_rhat(g.standard_normal((T, C)) + np.array([0.0, 3.0]))
     assert rhat > 1.5 and ess < 20
     assert all(np.isnan(v) for v in pkg.ess_rhat(np.ones((T, C))))
+
+
+def test_metrics_over_replications():
+    """getMetrics / getMetrics2 (src/SimTools.jl:500-551) on a hand-made replication dictionary."""
+    true = np.array([1.0, 2.0, 4.0])
+    run = {"True": {"a": true}, 1: {"a": true + 0.1}, 2: {"a": true - 0.1}, 3: {"a": true * 1.0}}
+    m = pkg.getMetrics(run, par="a")
+    assert abs(m["Bias"]) < 1e-12 and abs(m["Rmse"] - np.sqrt(2 * 0.01 / 3)) < 1e-12 and abs(m["Corr"] - 1) < 1e-12
+    m2 = pkg.getMetrics2(run, par="a")
+    assert abs(m2["relativeBias"]) < 1e-12 and abs(m2["normalizedRmse"] - np.sqrt(2 * 0.01 / 3) / (4.1 - 0.9)) < 1e-12
