@@ -21,7 +21,7 @@ TRACE_RA, TRACE_RT, TRACE_QR, TRACE_LOGLIKE = 0, 1, 2, 3
 EXPORTS = [
     "erm_create", "erm_destroy", "erm_set_data", "erm_set_state", "erm_get_state", "erm_run", "erm_rows_done",
     "erm_reset_trace", "erm_trace_width", "erm_get_trace", "erm_item_trace_width", "erm_get_item_trace", "erm_get_mean",
-    "erm_post_count", "erm_get_diagnostics", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample",
+    "erm_post_count", "erm_get_diagnostics", "erm_simulate_data", "erm_get_truth", "erm_get_data", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample",
 ]
 
 
@@ -87,6 +87,9 @@ def load():
     lib.erm_post_count.argtypes = [H]
     lib.erm_post_count.restype = C.c_int64
     lib.erm_get_diagnostics.argtypes = [H, C.c_int, C.c_void_p, C.c_void_p]
+    lib.erm_simulate_data.argtypes = [H, C.POINTER(erm_state), C.c_uint64, C.c_int]
+    lib.erm_get_truth.argtypes = [H, C.c_void_p, C.c_void_p]
+    lib.erm_get_data.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.erm_get_timing.argtypes = [H, C.POINTER(erm_timing)]
     lib.erm_last_error.restype = C.c_char_p
     lib.erm_version.restype = C.c_char_p
@@ -155,6 +158,26 @@ class Engine:
         xx = None if X is None or np.size(X) == 0 else np.asfortranarray(X, dtype=np.float64)
         check(self._lib.erm_set_data(self._h, Yf.ctypes.data, None if lt is None else lt.ctypes.data,
                                      None if xx is None else xx.ctypes.data))
+
+    def simulate_data(self, seed=4321, noise=0, **truth):
+        """Generate the data set on the device from the true parameters (erm_simulate_data); returns (theta, zeta) of the truth."""
+        arrs = {k: (None if v is None else np.asfortranarray(v, dtype=np.float64)) for k, v in truth.items()}
+        st, keep = state_struct(arrs)
+        check(self._lib.erm_simulate_data(self._h, C.byref(st), int(seed), int(noise)))
+        th, ze = np.empty(self.cfg.n_subj), np.empty(self.cfg.n_subj)
+        check(self._lib.erm_get_truth(self._h, th.ctypes.data, ze.ctypes.data))
+        return th, ze
+
+    def get_data(self):
+        """The resident data set as (Y uint8 NxJ, logT float64 NxJ or None, X float64 NxF or None), column-major."""
+        c = self.cfg
+        N, J = c.n_subj, c.n_item
+        F = 0 if c.model in (MODEL_CROSSQR, MODEL_CROSS, MODEL_NULL) else c.n_feat
+        Y = np.empty((N, J), dtype=np.uint8, order="F")
+        logT = None if c.model == MODEL_MLIRT else np.empty((N, J), dtype=np.float64, order="F")
+        X = np.empty((N, F), dtype=np.float64, order="F") if F > 0 else None
+        check(self._lib.erm_get_data(self._h, Y.ctypes.data, None if logT is None else logT.ctypes.data, None if X is None else X.ctypes.data))
+        return Y, logT, X
 
     def set_state(self, **arrays):
         arrs = {k: (None if v is None else np.asfortranarray(v, dtype=np.float64)) for k, v in arrays.items()}

@@ -1262,6 +1262,113 @@ __global__ void diag_kernel(const T* tr, long long ncol, long long ld, int nIter
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Synthetic data on the device: the generators of src/SimTools.jl -- setDataRtIrt :149-178, setDataRtIrtNull
+// :117-144, setDataMlIrt :349-368, setDataRtIrtCross :220-255, setDataRtIrtLatent :304-343 -- written straight into the engine's
+// resident buffers, one thread per subject.  Streams (DATA_SUBJ, i) / (DATA_CELL, i, j) of the data seed: like the host generators,
+// this is the reference's distribution, not Julia's Random.seed! stream.
+//   gen 0 MlIrt : X[:,1] ~ Bernoulli(1/2), X[:,2:] ~ N(0,1), theta ~ N(X beta, 1)
+//   gen 1 RtIrt : X ~ N(0,1), (theta, zeta) = X beta + N2(0, Sigp), logT ~ N(lambda_j - zeta_i, sig2t_j) truncated to (0, inf)
+//   gen 2 Null  : (theta, zeta) ~ N2(0, Sigp), logT as RtIrt
+//   gen 3 Cross : (theta, zeta) ~ N2(0, Sigp), logT = lambda_j - zeta_i - theta_i rho_j + 0.3 e
+//   gen 4 Latent: theta ~ N(0,1), X ~ N(0,1), zeta = [X theta] beta + 0.3 e, logT = lambda_j - zeta_i + N(0,1)
+//   e ("noise"): 0 N(0,1), 1 t_5, 2 Gamma(1/2, 1) - 1
+// Y_ij ~ Bernoulli(logistic(a_j (theta_i - b_j))) always.  logT is written raw; center_kernel subtracts the column means afterwards.
+// ---------------------------------------------------------------------------------------------------------------------
+struct GenArgs {
+    uint8_t* Y; void* C; void* X; double* theta; double* zeta;   // C, X in the engine's cell type
+    const double* truth;       // a[J] b[J] lambda[J] sig2t[J] rho[J] | Sigp chol L00 L10 L11 | beta (RtIrt: [F][2] row-major; MlIrt [F]; Latent [F+1])
+    long long N; int J, F, gen, noise; uint64_t seed;
+};
+__device__ inline double gen_noise(Stream& s, int kind)
+{
+    if (kind == 0) return normal<double>(s);
+    if (kind == 1) { const double zn = normal<double>(s); return zn / sqrt(chisq(s, 5.0) / 5.0); }
+    const double u = uniform<double>(s);
+    const double g = gamma_mt(s, 1.5) * u * u;                            // Gamma(a) = Gamma(a + 1) U^(1/a), a = 1/2 (Marsaglia-Tsang needs a >= 1)
+    return g - 1.0;
+}
+template <typename real>
+__global__ void gen_kernel(GenArgs G)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.N) return;
+    const int J = G.J, F = G.F;
+    const double* a = G.truth, *b = a + J, *lam = b + J, *sg = lam + J, *rho = sg + J, *L = rho + J, *beta = L + 3;
+    real* X = reinterpret_cast<real*>(G.X);
+    real* C = reinterpret_cast<real*>(G.C);
+    Stream ss(G.seed, 0u, SITE_DATA_SUBJ, (uint32_t)i, 0u, 0u);
+    double mt = 0.0, mz = 0.0;
+    for (int f = 0; f < F; ++f) {
+        double x = normal<double>(ss);
+        if (G.gen == 0 && f == 0) x = uniform<double>(ss) < 0.5 ? 1.0 : 0.0;
+        const real xr = (real)x;                          // the model sees the stored value
+        X[(size_t)i * F + f] = xr;
+        if (G.gen == 0) mt += (double)xr * beta[f];
+        else if (G.gen == 1) { mt += (double)xr * beta[2 * f]; mz += (double)xr * beta[2 * f + 1]; }
+        else if (G.gen == 4) mz += (double)xr * beta[f];
+    }
+    const double z0 = normal<double>(ss), z1 = normal<double>(ss);
+    double th, ze;
+    if (G.gen == 0) { th = mt + z0; ze = 0.0; }
+    else if (G.gen == 4) { th = z0; ze = mz + th * beta[F] + 0.3 * gen_noise(ss, G.noise); }
+    else { th = mt + L[0] * z0; ze = mz + L[1] * z0 + L[2] * z1; }
+    G.theta[i] = th; G.zeta[i] = ze;
+    for (int j = 0; j < J; ++j) {
+        Stream sc(G.seed, 0u, SITE_DATA_CELL, (uint32_t)i, (uint32_t)j, 0u);
+        const double eta = a[j] * (th - b[j]);
+        G.Y[(size_t)i * J + j] = uniform<double>(sc) < 1.0 / (1.0 + exp(-eta)) ? 1 : 0;
+        if (G.gen == 0) continue;
+        double lt;
+        if (G.gen == 1 || G.gen == 2) lt = truncnorm0(sc, lam[j] - ze, sqrt(sg[j]));
+        else if (G.gen == 3) lt = lam[j] - ze - th * rho[j] + 0.3 * gen_noise(sc, G.noise);
+        else lt = lam[j] - ze + normal<double>(sc);
+        C[(size_t)i * J + j] = (real)lt;
+    }
+}
+// per-workgroup partial column sums of the generated data: [block][3][J] = sum kappa, sum logT, sum logT^2 (fp64), then x'x partials
+template <typename real>
+__global__ void colsum_kernel(const uint8_t* Y, const real* C, const real* X, long long N, int J, int F, int has_c, double* part)
+{
+    const long long per = (N + gridDim.x - 1) / gridDim.x, r0 = (long long)blockIdx.x * per, r1 = (r0 + per < N) ? r0 + per : N;
+    const int p = F + 1;
+    double* out = part + (size_t)blockIdx.x * (3 * J + p * p);
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        double sk = 0.0, s1 = 0.0, s2 = 0.0;
+        for (long long i = r0; i < r1; ++i) {
+            sk += (double)Y[(size_t)i * J + j] - 0.5;
+            if (has_c) { const double c = (double)C[(size_t)i * J + j]; s1 += c; s2 += c * c; }
+        }
+        out[j] = sk; out[J + j] = s1; out[2 * J + j] = s2;
+    }
+    for (int e = threadIdx.x; e < p * p; e += blockDim.x) {
+        const int u = e % p, v = e / p;
+        double t = 0.0;
+        for (long long i = r0; i < r1; ++i) {
+            const double xu = u == 0 ? 1.0 : (double)X[(size_t)i * F + u - 1], xv = v == 0 ? 1.0 : (double)X[(size_t)i * F + v - 1];
+            t += xu * xv;
+        }
+        out[3 * J + e] = t;
+    }
+}
+// logT -> logT - column mean, and the centred sums of squares per workgroup ([block][J])
+template <typename real>
+__global__ void center_kernel(real* C, long long N, int J, const double* mean, double* part)
+{
+    const long long per = (N + gridDim.x - 1) / gridDim.x, r0 = (long long)blockIdx.x * per, r1 = (r0 + per < N) ? r0 + per : N;
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        const double m = mean[j];
+        double sq = 0.0;
+        for (long long i = r0; i < r1; ++i) {
+            const double c = (double)C[(size_t)i * J + j] - m;
+            const real cr = (real)c;
+            C[(size_t)i * J + j] = cr;
+            sq += (double)cr * (double)cr;
+        }
+        part[(size_t)blockIdx.x * J + j] = sq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // unit kernels for parity tests of the device samplers against the oracle
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename real>

@@ -21,7 +21,7 @@ constexpr int MAX_TRIES = 4096;   // bound on every rejection loop: a non-finite
 
 enum Site : uint32_t {
     SITE_OMEGA = 1, SITE_THETA = 2, SITE_ZETA = 3, SITE_NU = 4, SITE_B = 5, SITE_A = 6,
-    SITE_LAMBDA = 7, SITE_SIG2T = 8, SITE_BETA = 9, SITE_SIGP = 10, SITE_RHO = 11, SITE_TEST = 15
+    SITE_LAMBDA = 7, SITE_SIG2T = 8, SITE_BETA = 9, SITE_SIGP = 10, SITE_RHO = 11, SITE_DATA_SUBJ = 12, SITE_DATA_CELL = 13, SITE_TEST = 15
 };
 
 // ---- precision-generic math wrappers -------------------------------------------------------

@@ -53,6 +53,9 @@ struct EngineBase {
     virtual int get_item_trace(double*) = 0;
     virtual int get_mean(erm_state*) = 0;
     virtual int get_diagnostics(int, double*, double*) = 0;
+    virtual int simulate_data(const erm_state*, uint64_t, int) = 0;
+    virtual int get_data(uint8_t*, double*, double*) = 0;
+    virtual int get_truth(double*, double*) = 0;
     virtual int reset_trace() = 0;
     int64_t rows_done = 0;
     int64_t post_rows = 0;
@@ -569,23 +572,7 @@ template <typename real> struct Engine : EngineBase {
                 }
                 cst[cst_off_xtx(J) + u + v * PMAX] = t;
             }
-            {   // (x'x)^-1 by Gauss-Jordan with partial pivoting (fp64, p <= PMAX)
-                std::vector<double> M((size_t)pp * 2 * pp, 0.0);
-                for (int i = 0; i < pp; ++i) { for (int jx = 0; jx < pp; ++jx) M[(size_t)i * 2 * pp + jx] = cst[cst_off_xtx(J) + i + jx * PMAX]; M[(size_t)i * 2 * pp + pp + i] = 1.0; }
-                for (int c = 0; c < pp; ++c) {
-                    int piv = c;
-                    for (int r = c + 1; r < pp; ++r) if (std::fabs(M[(size_t)r * 2 * pp + c]) > std::fabs(M[(size_t)piv * 2 * pp + c])) piv = r;
-                    if (!(std::fabs(M[(size_t)piv * 2 * pp + c]) > 0.0)) return fail(ERM_ERR_ARG, "x'x is singular (collinear covariates)");
-                    if (piv != c) for (int jx = 0; jx < 2 * pp; ++jx) std::swap(M[(size_t)c * 2 * pp + jx], M[(size_t)piv * 2 * pp + jx]);
-                    const double d = M[(size_t)c * 2 * pp + c];
-                    for (int jx = 0; jx < 2 * pp; ++jx) M[(size_t)c * 2 * pp + jx] /= d;
-                    for (int r = 0; r < pp; ++r) if (r != c) {
-                        const double f = M[(size_t)r * 2 * pp + c];
-                        if (f != 0.0) for (int jx = 0; jx < 2 * pp; ++jx) M[(size_t)r * 2 * pp + jx] -= f * M[(size_t)c * 2 * pp + jx];
-                    }
-                }
-                for (int i = 0; i < pp; ++i) for (int jx = 0; jx < pp; ++jx) cst[cst_off_xinv(J) + i + jx * PMAX] = M[(size_t)i * 2 * pp + pp + jx];
-            }
+            if (int rc = invert_xtx(cst)) return rc;
             if (Fk > 0) {
                 for (int f = 0; f < Fk; ++f) for (int64_t i = 0; i < N; ++i) xr[(size_t)i * Fk + f] = (real)X[(size_t)f * N + i];
                 HIPCHK(hipMemcpy(dX.p, xr.data(), (size_t)N * Fk * sizeof(real), hipMemcpyHostToDevice));
@@ -593,6 +580,136 @@ template <typename real> struct Engine : EngineBase {
         }
         HIPCHK(hipMemcpy(dCst.p, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
         has_data = true;
+        return 0;
+    }
+
+    // (x'x)^-1 by Gauss-Jordan with partial pivoting (fp64, p <= PMAX); x'x is in cst at cst_off_xtx with leading dimension PMAX
+    int invert_xtx(std::vector<double>& cst) {
+        const int pp = p();
+        std::vector<double> M((size_t)pp * 2 * pp, 0.0);
+        for (int i = 0; i < pp; ++i) { for (int jx = 0; jx < pp; ++jx) M[(size_t)i * 2 * pp + jx] = cst[cst_off_xtx(J) + i + jx * PMAX]; M[(size_t)i * 2 * pp + pp + i] = 1.0; }
+        for (int c = 0; c < pp; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < pp; ++r) if (std::fabs(M[(size_t)r * 2 * pp + c]) > std::fabs(M[(size_t)piv * 2 * pp + c])) piv = r;
+            if (!(std::fabs(M[(size_t)piv * 2 * pp + c]) > 0.0)) return fail(ERM_ERR_ARG, "x'x is singular (collinear covariates)");
+            if (piv != c) for (int jx = 0; jx < 2 * pp; ++jx) std::swap(M[(size_t)c * 2 * pp + jx], M[(size_t)piv * 2 * pp + jx]);
+            const double d = M[(size_t)c * 2 * pp + c];
+            for (int jx = 0; jx < 2 * pp; ++jx) M[(size_t)c * 2 * pp + jx] /= d;
+            for (int r = 0; r < pp; ++r) if (r != c) {
+                const double f = M[(size_t)r * 2 * pp + c];
+                if (f != 0.0) for (int jx = 0; jx < 2 * pp; ++jx) M[(size_t)r * 2 * pp + jx] -= f * M[(size_t)c * 2 * pp + jx];
+            }
+        }
+        for (int i = 0; i < pp; ++i) for (int jx = 0; jx < pp; ++jx) cst[cst_off_xinv(J) + i + jx * PMAX] = M[(size_t)i * 2 * pp + pp + jx];
+        return 0;
+    }
+
+    // -------------------------------------------------------------------------------------------- synthetic data on the device
+    DevBuf dTruthTheta, dTruthZeta;
+    std::vector<double> col_mean;      // column means of logT (kept for erm_get_data)
+    int simulate_data(const erm_state* tr, uint64_t seed, int noise) override {
+        if (!tr || !tr->a || !tr->b) return fail(ERM_ERR_ARG, "truth needs a and b");
+        if (is_rt() && (!tr->lambda || !tr->sig2t)) return fail(ERM_ERR_ARG, "truth needs lambda and sig2t for response-time models");
+        if (noise < 0 || noise > 2) return fail(ERM_ERR_ARG, "noise must be 0 (norm), 1 (tail) or 2 (skew)");
+        int gen;
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: gen = 0; break;
+        case ERM_MODEL_RTIRT: gen = 1; break;
+        case ERM_MODEL_NULL: gen = 2; break;
+        case ERM_MODEL_CROSS: case ERM_MODEL_CROSSQR: gen = 3; break;
+        default: gen = 4;
+        }
+        if ((gen == 0 || gen == 1 || gen == 4) && Fk > 0 && !tr->beta) return fail(ERM_ERR_ARG, "truth needs beta");
+        if (gen == 3 && !tr->rho) return fail(ERM_ERR_ARG, "truth needs rho");
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamSynchronize(stream));
+        // truth vector: a b lambda sig2t rho | chol(Sigp) | beta
+        std::vector<double> tv((size_t)5 * J + 3 + 2 * PMAX + 2, 0.0);
+        for (int j = 0; j < J; ++j) {
+            tv[j] = tr->a[j]; tv[J + j] = tr->b[j];
+            tv[2 * J + j] = tr->lambda ? tr->lambda[j] : 0.0; tv[3 * J + j] = tr->sig2t ? tr->sig2t[j] : 1.0; tv[4 * J + j] = tr->rho ? tr->rho[j] : 0.0;
+            if (is_rt() && !(tv[3 * J + j] > 0.0)) return fail(ERM_ERR_ARG, "sig2t must be positive");
+        }
+        double S00 = 1.0, S10 = 0.0, S11 = 1.0;
+        if (tr->sigp) { S00 = tr->sigp[0]; S10 = tr->sigp[1]; S11 = tr->sigp[3]; }
+        if (!(S00 > 0.0) || !(S11 - S10 * S10 / S00 > 0.0)) return fail(ERM_ERR_ARG, "Sigp must be positive definite");
+        tv[5 * J] = std::sqrt(S00); tv[5 * J + 1] = S10 / tv[5 * J]; tv[5 * J + 2] = std::sqrt(S11 - tv[5 * J + 1] * tv[5 * J + 1]);
+        // beta: the generators' truth has no intercept row (src/SimTools.jl:86,107,283): RtIrt [nFeat][2] column-major -> (f, c) at 2f + c
+        double* bt = &tv[5 * J + 3];
+        if (tr->beta) {
+            if (gen == 1) for (int f = 0; f < Fk; ++f) { bt[2 * f] = tr->beta[f]; bt[2 * f + 1] = tr->beta[Fk + f]; }
+            else if (gen == 0) for (int f = 0; f < Fk; ++f) bt[f] = tr->beta[f];
+            else if (gen == 4) for (int f = 0; f <= Fk; ++f) bt[f] = tr->beta[f];
+        }
+        DevBuf dT;
+        if (int rc = dT.alloc(tv.size() * sizeof(double))) return rc;
+        HIPCHK(hipMemcpy(dT.p, tv.data(), tv.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (!dTruthTheta.p) { if (int rc = dTruthTheta.alloc((size_t)N * sizeof(double))) return rc; if (int rc = dTruthZeta.alloc((size_t)N * sizeof(double))) return rc; }
+        GenArgs g{};
+        g.Y = dY.as<uint8_t>(); g.C = dC.p; g.X = dX.p; g.theta = dTruthTheta.as<double>(); g.zeta = dTruthZeta.as<double>();
+        g.truth = dT.as<double>(); g.N = N; g.J = J; g.F = Fk; g.gen = gen; g.noise = noise; g.seed = seed;
+        hipLaunchKernelGGL((gen_kernel<real>), dim3((unsigned)((N + 127) / 128)), dim3(128), 0, stream, g);
+        // ---- constants of the data set (the same as erm_set_data's): K0, column means / centred squares of logT, x'x and its inverse
+        const int NB = 256, pp = p(), PW = 3 * J + pp * pp;
+        DevBuf dPart, dMean, dPart2;
+        if (int rc = dPart.alloc((size_t)NB * PW * sizeof(double))) return rc;
+        hipLaunchKernelGGL((colsum_kernel<real>), dim3(NB), dim3(128), 0, stream, dY.as<uint8_t>(), dC.as<real>(), dX.as<real>(), (long long)N, J, Fk,
+                           is_rt() ? 1 : 0, dPart.as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<double> part((size_t)NB * PW), cst(cst_size(J), 0.0);
+        HIPCHK(hipMemcpy(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost));
+        col_mean.assign(J, 0.0);
+        for (int j = 0; j < J; ++j) {
+            double sk = 0.0, s1 = 0.0;
+            for (int b = 0; b < NB; ++b) { sk += part[(size_t)b * PW + j]; s1 += part[(size_t)b * PW + J + j]; }
+            cst[cst_off_k0(J) + j] = sk; col_mean[j] = s1 / (double)N; cst[cst_off_m(J) + j] = col_mean[j];
+        }
+        for (int e = 0; e < pp * pp; ++e) { double t = 0.0; for (int b = 0; b < NB; ++b) t += part[(size_t)b * PW + 3 * J + e]; cst[cst_off_xtx(J) + (e % pp) + (e / pp) * PMAX] = t; }
+        if (int rc = invert_xtx(cst)) return rc;
+        if (is_rt()) {
+            if (int rc = dMean.alloc((size_t)J * sizeof(double))) return rc;
+            if (int rc = dPart2.alloc((size_t)NB * J * sizeof(double))) return rc;
+            HIPCHK(hipMemcpy(dMean.p, col_mean.data(), (size_t)J * sizeof(double), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL((center_kernel<real>), dim3(NB), dim3(128), 0, stream, dC.as<real>(), (long long)N, J, dMean.as<double>(), dPart2.as<double>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(stream));
+            std::vector<double> p2((size_t)NB * J);
+            HIPCHK(hipMemcpy(p2.data(), dPart2.p, p2.size() * sizeof(double), hipMemcpyDeviceToHost));
+            double tot = 0.0;
+            for (int j = 0; j < J; ++j) { double sq = 0.0; for (int b = 0; b < NB; ++b) sq += p2[(size_t)b * J + j]; cst[cst_off_csq(J) + j] = sq; tot += col_mean[j]; }
+            const double mu = tot / (double)J;              // equal column lengths: the grand mean is the mean of the column means
+            double ss = 0.0;
+            for (int j = 0; j < J; ++j) { const double dm = col_mean[j] - mu; ss += cst[cst_off_csq(J) + j] + (double)N * dm * dm; }
+            cst[cst_off_mu(J)] = mu; cst[cst_off_mu(J) + 1] = std::sqrt(ss / ((double)N * J - 1.0));
+        }
+        HIPCHK(hipMemcpy(dCst.p, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
+        has_data = true;
+        return 0;
+    }
+    // the resident data set back in the caller's (column-major) layout: Y bytes, logT = centred value + column mean, X
+    int get_data(uint8_t* Y, double* logT, double* X) override {
+        if (!has_data) return fail(ERM_ERR_STATE, "no data set is resident");
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamSynchronize(stream));
+        const size_t NJ = (size_t)N * J;
+        if (Y) { std::vector<uint8_t> t(NJ); HIPCHK(hipMemcpy(t.data(), dY.p, NJ, hipMemcpyDeviceToHost)); for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) Y[(size_t)j * N + i] = t[(size_t)i * J + j]; }
+        if (logT && is_rt()) {
+            std::vector<double> cst(cst_size(J));
+            HIPCHK(hipMemcpy(cst.data(), dCst.p, cst.size() * sizeof(double), hipMemcpyDeviceToHost));
+            std::vector<real> t(NJ);
+            HIPCHK(hipMemcpy(t.data(), dC.p, NJ * sizeof(real), hipMemcpyDeviceToHost));
+            for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) logT[(size_t)j * N + i] = (double)t[(size_t)i * J + j] + cst[cst_off_m(J) + j];
+        }
+        if (X && Fk > 0) { std::vector<real> t((size_t)N * Fk); HIPCHK(hipMemcpy(t.data(), dX.p, t.size() * sizeof(real), hipMemcpyDeviceToHost)); for (int f = 0; f < Fk; ++f) for (int64_t i = 0; i < N; ++i) X[(size_t)f * N + i] = (double)t[(size_t)i * Fk + f]; }
+        return 0;
+    }
+    int get_truth(double* theta, double* zeta) override {
+        if (!dTruthTheta.p) return fail(ERM_ERR_STATE, "erm_simulate_data has not been called");
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (theta) HIPCHK(hipMemcpy(theta, dTruthTheta.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+        if (zeta) HIPCHK(hipMemcpy(zeta, dTruthZeta.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
         return 0;
     }
 
@@ -897,6 +1014,9 @@ int64_t erm_item_trace_width(erm_handle h) { return h ? h->e->item_trace_width()
 int erm_get_item_trace(erm_handle h, double* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_item_trace(out); }
 int erm_get_mean(erm_handle h, erm_state* out) { CHK_H; return h->e->get_mean(out); }
 int64_t erm_post_count(erm_handle h) { return h ? h->e->post_rows : -1; }
+int erm_simulate_data(erm_handle h, const erm_state* truth, uint64_t seed, int noise) { CHK_H; return h->e->simulate_data(truth, seed, noise); }
+int erm_get_data(erm_handle h, uint8_t* Y, double* logT, double* X) { CHK_H; return h->e->get_data(Y, logT, X); }
+int erm_get_truth(erm_handle h, double* theta, double* zeta) { CHK_H; return h->e->get_truth(theta, zeta); }
 int erm_get_diagnostics(erm_handle h, int which, double* ess, double* rhat) { CHK_H; if (!ess || !rhat) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_diagnostics(which, ess, rhat); }
 int erm_get_timing(erm_handle h, erm_timing* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); *out = h->e->timing; return 0; }
 const char* erm_last_error(void) { return g_err.c_str(); }

@@ -47,6 +47,7 @@ class _GibbsBase:
         self.engine_opts = dict(engine_opts)
         self._engine = None
         self._engine_key = None
+        self._data_on_device = False
         self.Para = None
         self.setInitialValues()          # constructors always overwrite Para (src/GibbsRtIrt.pl.jl:100-102)
         self.Post = _OutputPost()
@@ -71,19 +72,28 @@ class _GibbsBase:
             d["nu"] = np.asarray(P.nu, dtype=np.float64).reshape(-1, order="F")
         return d
 
-    def _engine_for(self, intercept, onepl, cov2one):
+    def _engine_for(self, intercept, onepl, cov2one, *, upload=True):
         key = (bool(intercept), bool(onepl), bool(cov2one))
         if self._engine is not None and self._engine_key == key:
             return self._engine
+        resident = None
         if self._engine is not None:
+            if not upload or self._data_on_device:
+                resident = self._engine.get_data()     # the data set lives on the device only: carry it over to the new engine
             self._engine.close()
         C = self.Cond
-        if self.Data is None:
+        if self.Data is None and upload and resident is None:
             raise ValueError("Data is required")
         eng = _lib.Engine(model=self._model, n_item=C.nItem, n_subj=C.nSubj, n_feat=C.nFeat, n_iter=C.nIter, n_chain=C.nChain,
                           n_burnin=C.nBurnin, intercept=int(intercept), one_pl=int(onepl), cov2one=int(cov2one), q_rt=C.qRt,
                           seed=self.seed, chain_id=self.chain_id, device=self.device, precision=_PREC[self.precision],
                           trace_mode=_TRACE[self.trace], **self.engine_opts)
+        self._engine, self._engine_key = eng, key
+        if resident is not None:
+            eng.set_data(*resident)
+            return eng
+        if not upload:
+            return eng
         D = self.Data
         Y = np.asarray(D.Y)
         if Y.shape != (C.nSubj, C.nItem):
@@ -157,6 +167,31 @@ class _GibbsBase:
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+
+
+def simulateData(MCMC: _GibbsBase, truePara: InputPara, *, type="norm", seed=4321, pull=True):
+    """setData* on the device (erm_simulate_data): generates X, theta, zeta, Y, logT from `truePara` straight into the engine's
+    resident buffers -- no host generation, no upload.  truePara.theta / .zeta receive the generated truth; with pull=True the data set is
+    also copied to MCMC.Data (needed by the host-side getDic / getLogLikelihood)."""
+    from .base import InputData
+    eng = MCMC._engine_for(False, False, MCMC._cov2one_default, upload=False)
+    noise = {"norm": 0, "tail": 1, "skew": 2}[type]
+    truth = dict(a=truePara.a, b=truePara.b)
+    if MCMC._model != _lib.MODEL_MLIRT:
+        truth.update(lambda_=truePara.lam, sig2t=truePara.sig2t if truePara.sig2t.size else np.ones(MCMC.Cond.nItem))
+        if np.size(truePara.Sigp):
+            truth["sigp"] = np.asarray(truePara.Sigp, dtype=np.float64).reshape(-1, order="F")
+    if truePara.beta.size:
+        truth["beta"] = np.asarray(truePara.beta, dtype=np.float64).reshape(-1, order="F")
+    if truePara.rho.size:
+        truth["rho"] = truePara.rho
+    truePara.theta, truePara.zeta = eng.simulate_data(seed=seed, noise=noise, **truth)
+    MCMC.truePara = truePara
+    MCMC._data_on_device = True
+    if pull:
+        Y, logT, X = eng.get_data()
+        MCMC.Data = InputData(Y=Y, T=np.exp(logT) if logT is not None else (), X=X if X is not None else ())
+    return MCMC
 
 
 def sample_b(MCMC: _GibbsBase, *, intercept=False, itemtype="2pl", cov2one=None):

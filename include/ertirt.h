@@ -89,6 +89,16 @@ void erm_destroy(erm_handle h);
  * logT may be NULL for MlIrt; X may be NULL when n_feat == 0 or for CrossQr. */
 int erm_set_data(erm_handle h, const uint8_t* Y, const double* logT, const double* X);
 
+/* Simulation studies.  Replaces setDataRtIrt / setDataRtIrtNull / setDataMlIrt / setDataRtIrtCross / setDataRtIrtLatent
+ * (src/SimTools.jl:117-368): draws covariates, subject parameters and responses ON the device from the true item / structural
+ * parameters in `truth` (a, b, lambda, sig2t, rho, sigp as in erm_state; beta WITHOUT intercept row: RtIrt [nFeat][2] column-major, MlIrt
+ * [nFeat], Latent(Qr) [nFeat+1]; theta / zeta / nu ignored) and installs them as the resident data set, exactly as erm_set_data would.
+ * noise: 0 "norm", 1 "tail" (t5), 2 "skew" (Gamma(1/2,1) - 1) for the Cross / Latent generators.  erm_get_truth returns the generated
+ * theta, zeta; erm_get_data the resident data set (either source) in the caller's column-major layout (any pointer may be NULL). */
+int erm_simulate_data(erm_handle h, const erm_state* truth, uint64_t seed, int noise);
+int erm_get_truth(erm_handle h, double* theta, double* zeta);
+int erm_get_data(erm_handle h, uint8_t* Y, double* logT, double* X);
+
 /* Para in / out (setInitialValues: src/GibbsRtIrt.pl.jl:84-93,122-133; Cross :123-134; Latent :113-124). */
 int erm_set_state(erm_handle h, const erm_state* st);
 int erm_get_state(erm_handle h, erm_state* st);
