@@ -21,7 +21,7 @@ TRACE_RA, TRACE_RT, TRACE_QR, TRACE_LOGLIKE = 0, 1, 2, 3
 EXPORTS = [
     "erm_create", "erm_destroy", "erm_set_data", "erm_set_state", "erm_get_state", "erm_run", "erm_rows_done",
     "erm_reset_trace", "erm_trace_width", "erm_get_trace", "erm_item_trace_width", "erm_get_item_trace", "erm_get_mean",
-    "erm_post_count", "erm_get_diagnostics", "erm_simulate_data", "erm_get_truth", "erm_get_data", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample",
+    "erm_post_count", "erm_get_diagnostics", "erm_simulate_data", "erm_get_truth", "erm_get_data", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample", "erm_sample_gig",
 ]
 
 
@@ -95,6 +95,7 @@ def load():
     lib.erm_version.restype = C.c_char_p
     lib.erm_debug_sample.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.erm_sample_gig.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p]
     _lib = lib
     return lib
 
@@ -256,4 +257,11 @@ def debug_sample(which, n, par0=None, par1=None, *, seed=1234, site=15, sweep=1,
     p1 = None if par1 is None else np.ascontiguousarray(par1, dtype=np.float64)
     check(lib.erm_debug_sample(device, precision, which, seed, site, sweep, n,
                                None if p0 is None else p0.ctypes.data, None if p1 is None else p1.ctypes.data, out.ctypes.data))
+    return out
+
+
+def sample_gig(p, a, b, n, *, seed=1234, site=15, sweep=1, device=0):
+    """n draws of GIG(p, a, b) on the device (erm_sample_gig; rand(GeneralizedInverseGaussian(p, a, b)) of src/GenInvGaussian.jl)."""
+    out = np.empty(int(n), dtype=np.float64)
+    check(load().erm_sample_gig(device, seed, site, sweep, int(n), float(p), float(a), float(b), out.ctypes.data))
     return out

@@ -1394,4 +1394,12 @@ __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uin
     out[k] = v;
 }
 
+__global__ void gig_batch_kernel(uint64_t seed, uint32_t site, uint32_t sweep, long long n, double p, double a, double b, double* out)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Stream st(seed, 0u, site, (uint32_t)k, 0u, sweep);
+    out[k] = gig(st, p, a, b);
+}
+
 }  // namespace erm

@@ -350,4 +350,39 @@ __device__ __forceinline__ double gamma_mt(Stream& s, double shape)
 __device__ __forceinline__ double invgamma(Stream& s, double shape, double scale) { return scale / gamma_mt(s, shape); }
 __device__ __forceinline__ double chisq(Stream& s, double k) { return 2.0 * gamma_mt(s, 0.5 * k); }
 
+// GIG(p, a, b), density proportional to x^(p-1) exp(-(a x + b/x)/2): the distribution type of src/GenInvGaussian.jl (dead code in the
+// reference), by Devroye's (2014) rejection sampler for the log-concave density of log X.  Same specification as
+// oracle/orc_rng.h::orc_gig; one attempt uses three uniforms.
+__device__ __forceinline__ double gig_psi(double x, double alpha, double lam) { return -alpha * (cosh(x) - 1.0) - lam * (exp(x) - x - 1.0); }
+__device__ __forceinline__ double gig_dpsi(double x, double alpha, double lam) { return -alpha * sinh(x) - lam * (exp(x) - 1.0); }
+__device__ inline double gig(Stream& st, double p, double a, double b)
+{
+    const double omega = sqrt(a * b);
+    const bool inv = p < 0.0;
+    const double lam = fabs(p);
+    const double alpha = sqrt(omega * omega + lam * lam) - lam;
+    double x = -gig_psi(1.0, alpha, lam), t, s;
+    if (x >= 0.5 && x <= 2.0) t = 1.0; else if (x > 2.0) t = sqrt(2.0 / (alpha + lam)); else t = log(4.0 / (alpha + 2.0 * lam));
+    x = -gig_psi(-1.0, alpha, lam);
+    if (x >= 0.5 && x <= 2.0) s = 1.0;
+    else if (x > 2.0) s = sqrt(4.0 / (alpha * cosh(1.0) + lam));
+    else { const double s1 = 1.0 / lam, s2 = log(1.0 + 1.0 / alpha + sqrt(1.0 / (alpha * alpha) + 2.0 / alpha)); s = s1 < s2 ? s1 : s2; }
+    const double eta = -gig_psi(t, alpha, lam), zeta = -gig_dpsi(t, alpha, lam);
+    const double theta = -gig_psi(-s, alpha, lam), xi = gig_dpsi(-s, alpha, lam);
+    const double pp = 1.0 / xi, r = 1.0 / zeta, td = t - r * eta, sd = s - pp * theta, q = td + sd;
+    double rnd = 0.0;
+    for (int tries = 0; tries < MAX_TRIES; ++tries) {
+        const double U = uniform<double>(st), V = uniform<double>(st), W = uniform<double>(st);
+        if (U < q / (pp + q + r)) rnd = -sd + q * V;
+        else if (U < (q + r) / (pp + q + r)) rnd = td - r * log(V);
+        else rnd = -sd + pp * log(V);
+        const double f1 = exp(-eta - zeta * (rnd - t)), f2 = exp(-theta + xi * (rnd + s));
+        const double g = (rnd >= -sd && rnd <= td) ? 1.0 : (rnd > td ? f1 : f2);
+        if (W * g <= exp(gig_psi(rnd, alpha, lam))) break;
+    }
+    double y = exp(rnd) * (lam / omega + sqrt(1.0 + lam * lam / (omega * omega)));
+    if (inv) y = 1.0 / y;
+    return y * sqrt(b / a);
+}
+
 }  // namespace erm

@@ -1042,4 +1042,18 @@ int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32
     return 0;
 }
 
+int erm_sample_gig(int device, uint64_t seed, uint32_t site, uint32_t sweep, int64_t n, double p, double a, double b, double* out)
+{
+    if (n <= 0 || !out) return fail(ERM_ERR_ARG, "bad n/out");
+    if (!(a > 0.0) || !(b > 0.0) || !std::isfinite(p) || p == 0.0) return fail(ERM_ERR_ARG, "GIG(p, a, b) needs a > 0, b > 0 and a finite p != 0");
+    HIPCHK(hipSetDevice(device));
+    DevBuf dout;
+    if (int rc = dout.alloc(n * sizeof(double))) return rc;
+    hipLaunchKernelGGL(gig_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, seed, site, sweep, (long long)n, p, a, b, dout.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // extern "C"

@@ -138,6 +138,11 @@ const char* erm_version(void);
 int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32_t site, uint32_t sweep, int64_t n,
                      const double* par0, const double* par1, double* out);
 
+/* n draws of the generalized inverse Gaussian GIG(p, a, b) (density ~ x^(p-1) exp(-(a x + b/x)/2); the distribution type of
+ * src/GenInvGaussian.jl:17-30, whose sampler :76-106 is dead code in the reference) by Devroye's (2014) sampler, fp64; element k uses
+ * stream (seed, site, i = k, sweep).  The live quantile weights are the p = -1/2 case and use the inverse-Gaussian sampler. */
+int erm_sample_gig(int device, uint64_t seed, uint32_t site, uint32_t sweep, int64_t n, double p, double a, double b, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -846,6 +846,15 @@ void orc_sample_batch(int which, uint64_t seed, int site, uint32_t sweep, int64_
     }
 }
 
+/* n draws of GIG(p, a, b); element k uses stream (seed, chain 0, site, i = k, j = 0, sweep) */
+void orc_sample_gig(uint64_t seed, int site, uint32_t sweep, int64_t n, double p, double a, double b, double* out)
+{
+    for (int64_t k = 0; k < n; ++k) {
+        orc_stream st = orc_stream_make(seed, 0, site, (uint32_t)k, 0, sweep);
+        out[k] = orc_gig(&st, p, a, b);
+    }
+}
+
 /* conditional moments for numpy cross-checks.  which: 0 theta(prior=x*beta) 1 theta(Null) 2 a 3 b 4 zeta 5 lambda
  * 6 sig2t(shape,scale) 7 rho 8 beta_rtirt (parM[2p], parV[2p*2p]) 9 Sigp scale matrix Psi (out1[4]) 10 latentqr Sigp scale (out1[1]) */
 void orc_moments(const orc_config* c, const orc_data* d, const orc_state* s, int which, double* out1, double* out2)

@@ -249,4 +249,42 @@ static inline double orc_gamma(orc_stream* s, double shape)
 static inline double orc_invgamma(orc_stream* s, double shape, double scale) { return scale / orc_gamma(s, shape); }
 static inline double orc_chisq(orc_stream* s, double k) { return 2.0 * orc_gamma(s, 0.5 * k); }
 
+
+/* Generalized inverse Gaussian GIG(p, a, b), density proportional to x^(p-1) exp(-(a x + b/x)/2) -- the distribution of
+ * /root/reference/src/GenInvGaussian.jl (params p, a, b; :17-30), whose own sampler (:76-106, gamma-proposal rejection) is dead code in
+ * the reference.  Restated with Devroye's (2014, "Random variate generation for the generalized inverse Gaussian
+ * distribution", Statistics and Computing 24) uniformly efficient rejection sampler for the log-concave density of log X:
+ * X = sqrt(b/a) Y, Y ~ GIG(|p|, omega = sqrt(a b)) (inverted for p < 0).  One attempt uses three uniforms. */
+static inline double orc_gig_psi(double x, double alpha, double lam) { return -alpha * (cosh(x) - 1.0) - lam * (exp(x) - x - 1.0); }
+static inline double orc_gig_dpsi(double x, double alpha, double lam) { return -alpha * sinh(x) - lam * (exp(x) - 1.0); }
+static inline double orc_gig(orc_stream* st, double p, double a, double b)
+{
+    const double omega = sqrt(a * b);
+    const int inv = p < 0.0;
+    const double lam = fabs(p);
+    const double alpha = sqrt(omega * omega + lam * lam) - lam;
+    double x = -orc_gig_psi(1.0, alpha, lam), t, s;
+    if (x >= 0.5 && x <= 2.0) t = 1.0; else if (x > 2.0) t = sqrt(2.0 / (alpha + lam)); else t = log(4.0 / (alpha + 2.0 * lam));
+    x = -orc_gig_psi(-1.0, alpha, lam);
+    if (x >= 0.5 && x <= 2.0) s = 1.0;
+    else if (x > 2.0) s = sqrt(4.0 / (alpha * cosh(1.0) + lam));
+    else { double s1 = 1.0 / lam, s2 = log(1.0 + 1.0 / alpha + sqrt(1.0 / (alpha * alpha) + 2.0 / alpha)); s = s1 < s2 ? s1 : s2; }
+    const double eta = -orc_gig_psi(t, alpha, lam), zeta = -orc_gig_dpsi(t, alpha, lam);
+    const double theta = -orc_gig_psi(-s, alpha, lam), xi = orc_gig_dpsi(-s, alpha, lam);
+    const double pp = 1.0 / xi, r = 1.0 / zeta, td = t - r * eta, sd = s - pp * theta, q = td + sd;
+    double rnd = 0.0;
+    for (int tries = 0; tries < 4096; ++tries) {
+        const double U = orc_unif(st), V = orc_unif(st), W = orc_unif(st);
+        if (U < q / (pp + q + r)) rnd = -sd + q * V;
+        else if (U < (q + r) / (pp + q + r)) rnd = td - r * log(V);
+        else rnd = -sd + pp * log(V);
+        const double f1 = exp(-eta - zeta * (rnd - t)), f2 = exp(-theta + xi * (rnd + s));
+        const double g = (rnd >= -sd && rnd <= td) ? 1.0 : (rnd > td ? f1 : f2);
+        if (W * g <= exp(orc_gig_psi(rnd, alpha, lam))) break;
+    }
+    double y = exp(rnd) * (lam / omega + sqrt(1.0 + lam * lam / (omega * omega)));
+    if (inv) y = 1.0 / y;
+    return y * sqrt(b / a);
+}
+
 #endif

@@ -92,3 +92,17 @@ def test_qr_weight_survives_degenerate_residuals():
     o = pu.orc_sample(8, n, pa, pb)
     assert np.all(np.isfinite(o))
     assert np.max(np.abs(_dev(8, n, pa, pb) - o) / o) < 1e-9
+
+
+@pytest.mark.parametrize("p,a,b", [(0.5, 2.0, 3.0), (-0.5, 1.0, 1.0), (2.5, 0.7, 4.0), (-3.0, 5.0, 0.2), (0.1, 0.01, 0.02)])
+def test_gig_matches_oracle(p, a, b):
+    """erm_sample_gig (general-p GIG of src/GenInvGaussian.jl, Devroye 2014) against the oracle's restatement, draw by draw."""
+    import ctypes as C
+    lib = pu.oracle()
+    lib.orc_sample_gig.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.orc_sample_gig.restype = None
+    n = 20000
+    want = np.empty(n)
+    lib.orc_sample_gig(1234, 15, 1, n, p, a, b, want.ctypes.data)
+    got = pu.ge.load_package()._lib.sample_gig(p, a, b, n, seed=1234, site=15, sweep=1)
+    assert np.max(np.abs(got - want) / np.abs(want)) < 1e-9

@@ -94,3 +94,26 @@ def test_truncated_normal(m, s):
 def test_gamma(shape):
     x = pu.orc_sample(6, 200_000, np.full(200_000, shape), seed=4)
     assert stats.kstest(x, stats.gamma(shape).cdf).pvalue > 1e-3
+
+
+@pytest.mark.parametrize("p,a,b", [(0.5, 2.0, 3.0), (-0.5, 1.0, 1.0), (2.5, 0.7, 4.0), (-3.0, 5.0, 0.2), (10.0, 3.0, 1.0)])
+def test_gig_moments_match_bessel_ratios(p, a, b):
+    """GIG(p, a, b) of src/GenInvGaussian.jl (density ~ x^(p-1) exp(-(a x + b/x)/2)): E[X^k] = (b/a)^(k/2) K_{p+k}(w) / K_p(w), w = sqrt(ab)
+    (the reference's own mean/var formulas, GenInvGaussian.jl:36-52); p = -1/2 is the inverse Gaussian of the live quantile weights."""
+    import ctypes as C
+    from scipy.special import kv
+    lib = pu.oracle()
+    lib.orc_sample_gig.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.orc_sample_gig.restype = None
+    n = 200_000
+    x = np.empty(n)
+    lib.orc_sample_gig(1234, 15, 1, n, p, a, b, x.ctypes.data)
+    w = np.sqrt(a * b)
+    for k in (1, 2, -1):
+        want = (b / a) ** (k / 2) * kv(p + k, w) / kv(p, w)
+        sd = np.std(x ** k) / np.sqrt(n)
+        assert abs(np.mean(x ** k) - want) < 5 * sd, (k, np.mean(x ** k), want)
+    if p == -0.5:                              # GIG(-1/2, a, b) == InverseGaussian(mu = sqrt(b/a), lambda = b)
+        ig = pu.orc_sample(4, n, np.full(n, np.sqrt(b / a)), np.full(n, b), seed=99)
+        from scipy.stats import ks_2samp
+        assert ks_2samp(x, ig).pvalue > 1e-3
