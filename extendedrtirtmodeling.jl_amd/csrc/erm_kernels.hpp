@@ -960,10 +960,11 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
     stamp(8);
 
     // ---- global statistics for the next tiny step: statistic g = sum over the workgroup's subjects of va * vb (* 1/nu for the
-    // sigp_mode-1 block); 32 lanes per statistic, lane l sums subjects l, l+32, ... in order, then a 32-lane butterfly: fixed order
+    // sigp_mode-1 block); one wave per statistic (statistic g on wave g mod nWaves, so the work is spread over the whole workgroup),
+    // lane l sums subjects l, l+64, ... in order, then a 64-lane butterfly: fixed order
     if (NG > 1) {
         const int cT = F + 1, cZ = F + 2, cU = F + 3, cN = F + 4;
-        const int tg = threadIdx.x >> 5, tl = threadIdx.x & 31, ngrp = blockDim.x >> 5;
+        const int tg = wave, tl = lane, ngrp = nWaves;
         for (int g = tg; g < NG - 1; g += ngrp) {
             int ca = 0, cb2 = 0; bool weighted = false;
             if (MODEL == MLIRT) { ca = g; cb2 = cT; }
@@ -995,12 +996,12 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                 }
             } else { ca = cZ; cb2 = cZ; }      // CrossQr pass B: sum zeta^2
             double accg = 0.0;
-            for (int li = tl; li < nrows_blk; li += 32) {
+            for (int li = tl; li < nrows_blk; li += 64) {
                 const real* o = sh_val + (size_t)li * NV;
                 const double va = ca == 0 ? 1.0 : (double)o[ca - 1], vb = cb2 == 0 ? 1.0 : (double)o[cb2 - 1];
                 accg += weighted ? va * vb / (double)o[cN - 1] : va * vb;
             }
-            accg = bfly_sum(accg, 1, 32);
+            accg = bfly_sum(accg, 1, 64);
             if (tl == 0) sh_gacc[g] = accg;          // wave 0's slot of the per-wave table summed by the epilogue (the other waves' stay 0)
         }
     }

@@ -474,8 +474,11 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipMemcpy(&back, dCtlB[cur].p, sizeof(Ctl), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&back0, dCtlB[0].p, sizeof(Ctl), hipMemcpyDeviceToHost));
         back.err = back0.err;
-        if (cur != 0) { Ctl b1{}; HIPCHK(hipMemcpy(&b1, dCtlB[1 - cur].p, sizeof(Ctl), hipMemcpyDeviceToHost)); back.dbg_attempts += b1.dbg_attempts; back.dbg_trips += b1.dbg_trips; back.dbg_cells += b1.dbg_cells; }
-        else { Ctl b1{}; HIPCHK(hipMemcpy(&b1, dCtlB[1].p, sizeof(Ctl), hipMemcpyDeviceToHost)); back.dbg_attempts += b1.dbg_attempts; back.dbg_trips += b1.dbg_trips; back.dbg_cells += b1.dbg_cells; }
+        {   // the diagnostic counters (ERM_PASS_STOP=9) accumulate in whichever buffer a launch read: add the other one
+            Ctl b1{};
+            HIPCHK(hipMemcpy(&b1, dCtlB[1 - cur].p, sizeof(Ctl), hipMemcpyDeviceToHost));
+            back.dbg_attempts += b1.dbg_attempts; back.dbg_trips += b1.dbg_trips; back.dbg_cells += b1.dbg_cells;
+        }
         const int64_t burn = (int64_t)cfg.n_burnin * cfg.n_chain;
         const int64_t lo = std::max<int64_t>(rows_done, burn), hi = rows_done + nsweeps;
         if (hi > lo) post_rows += hi - lo;
