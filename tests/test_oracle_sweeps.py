@@ -135,3 +135,18 @@ def test_openmp_oracle_is_bit_identical_to_the_single_thread_run():
     for k in ("ra", "rt", "qr"):
         assert np.array_equal(a[k], b[k]), k
     assert np.allclose(a["ll"], b["ll"], rtol=1e-12)
+
+
+def test_oracle_on_the_reference_demo_data():
+    """data/demo.csv of the reference (its `test SimTools.jl`:186-203 fits GibbsRtIrtNull to it): the oracle's chain is finite, keeps
+    Sigma_p on the unit diagonal (cov2one) and improves the log-likelihood from the constructor's initial values."""
+    rows = np.genfromtxt(os.path.join(GOLD, "demo.csv"), delimiter=",", skip_header=1, usecols=range(1, 25))
+    Y, logT, X = rows[:, :10].astype(np.uint8), rows[:, 10:20], rows[:, 20:24]
+    g = np.random.default_rng(0)
+    init = dict(theta=g.standard_normal(300), zeta=g.standard_normal(300), sigp=np.eye(2))
+    tr = pu.OracleProblem("null", Y, logT, X, init, qRt=0.5, cov2one=True).run(150)
+    assert np.all(np.isfinite(tr["ra"])) and np.all(np.isfinite(tr["rt"])) and np.all(np.isfinite(tr["ll"]))
+    assert np.all(tr["qr"][:, :10] == 0) and np.all(tr["qr"][:, 10] == 1) and np.all(tr["qr"][:, 13] == 1)
+    assert tr["ll"][-30:].mean() > tr["ll"][:3].mean()
+    lam = tr["rt"][75:, 300:310].mean(0)
+    assert np.max(np.abs(lam - logT.mean(0))) < 0.15          # lambda_j tracks the item's mean log time (zeta is centred near 0)
