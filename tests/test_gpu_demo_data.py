@@ -76,3 +76,52 @@ def test_demo_data_null_model_like_the_reference_script():
     assert 2.0 < c["λ"].mean() < 4.5                       # the demo's log response times average ~3
     ll = M.Post.logLike[:, 0, :]
     assert ll[-50:].mean() > ll[:3].mean()
+
+
+def load_timss():
+    """data/timms2019math.csv of the reference: 14 scored items (ME62*), their screen times in seconds (*_S) and ten standardised
+    background scales (*_Z) of 631 students -- complete cases, no missing values."""
+    import csv
+    with open(os.path.join(HERE, "golden", "timms2019math.csv")) as f:
+        rows = list(csv.reader(f))
+    h = rows[0]
+    a = np.array(rows[1:], dtype=np.float64)
+    iy = [k for k, n in enumerate(h) if n.startswith("ME62") and not n.endswith("_S")]
+    it = [k for k, n in enumerate(h) if n.startswith("ME62") and n.endswith("_S")]
+    ix = [k for k, n in enumerate(h) if n.endswith("_Z")]
+    return a[:, iy].astype(np.uint8), np.log(a[:, it]), a[:, ix]
+
+
+@pytest.mark.parametrize("model", ["rtirt", "mlirt", "latentqr", "crossqr", "null"])
+def test_timss_data_f64_parity(model):
+    """A real assessment data set (14 items, 10 covariates, response times from 1.7 s to 19 min) through the engine and the oracle."""
+    Y, logT, X = load_timss()
+    N, J = Y.shape
+    assert (N, J, X.shape[1]) == (631, 14, 10) and set(np.unique(Y)) == {0, 1} and np.all(np.isfinite(logT))
+    Xm = None if model == "crossqr" else X
+    F = 0 if Xm is None else 10
+    init = _init(model, N, J, F, np.random.default_rng(3))
+    T = 3 if model == "crossqr" else 8
+    cov2one = model != "latentqr"
+    res_dev = pu.run_device(model, Y, None if model == "mlirt" else logT, Xm, init, T, precision="f64", qRt=0.85, cov2one=cov2one)
+    tr = pu.OracleProblem(model, Y, None if model == "mlirt" else logT, Xm, init, qRt=0.85, cov2one=cov2one).run(T, with_nu=model in ("latentqr", "crossqr"))
+    assert pu.rel_err(res_dev["ra"][:, :, 0], tr["ra"]).max() < 1e-8
+    if model != "mlirt":
+        assert pu.rel_err(res_dev["rt"][:, :, 0], tr["rt"]).max() < 1e-8
+    assert pu.rel_err(res_dev["qr"][:, :, 0], tr["qr"]).max() < 1e-8
+    assert pu.rel_err(res_dev["ll"][:, 0, 0], tr["ll"]).max() < 1e-9
+
+
+def test_timss_quantile_fit_like_the_readme():
+    """README.md:84-102: Cond = setCond(qRa=0.85, qRt=0.85, nChain=3, nIter=...); MCMC = GibbsRtIrtQuantile(Cond, Data=Data); sample!;
+    coef; Post.mean.Sigp / beta -- on the reference's TIMSS file, fp32 engine."""
+    pkg = pu.ge.load_package()
+    Y, logT, X = load_timss()
+    Cond = pkg.setCond(nSubj=631, nItem=14, nFeat=10, qRa=0.85, qRt=0.85, nChain=3, nIter=200)
+    M = pkg.GibbsRtIrtQuantile(Cond, Data=pkg.InputData(Y=Y, T=np.exp(logT), X=X))
+    pkg.sample_b(M)
+    c = pkg.coef(M)
+    assert np.all(np.isfinite(c["a"])) and np.all(c["a"] > 0) and np.all(np.isfinite(c["β"])) and c["β"].shape == (12,) and c["β"][0] == 0
+    assert np.asarray(M.Post.mean.Sigp).shape == (4,) and M.Post.mean.Sigp[0] == 1 and M.Post.mean.Sigp[3] > 0
+    assert M.Post.qr.shape == (200, 10 + 2 + 4 + 631, 3)
+    assert abs(c["λ"].mean() - logT.mean()) < 1.0 and np.all(np.isfinite(M.Post.logLike))
