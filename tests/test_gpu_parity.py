@@ -228,3 +228,20 @@ def test_two_engines_in_one_process_do_not_interfere():
             e.run(2)
     for e in engs:
         assert np.array_equal(e.trace(L.TRACE_RA), ref)
+
+
+@pytest.mark.parametrize("model", ["rtirt", "crossqr"])
+def test_graph_replay_and_continuation(model):
+    """Long enough for the 32-sweep hipGraph path: run(45) + run(40) + run(3) == run(88), bit for bit (the fused kernel's double-buffered
+    parameter / counter / statistics blocks are re-based at every erm_run so the captured graph always sees the parity it was built with)."""
+    Y, logT, X, init, _ = pu.make_problem(model, 500, 9)
+    a = pu.run_device(model, Y, logT, X, init, 88, precision="f32")
+    L = pu.ge.load_package()._lib
+    eng = L.Engine(model=pu.MODELS[model], n_item=9, n_subj=500, n_feat=0 if X is None else 3, n_iter=88, n_chain=1, n_burnin=44, cov2one=1, q_rt=0.85,
+                   seed=1234, precision=0, trace_mode=1)
+    eng.set_data(Y, logT, X)
+    eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in init.items()})
+    for n in (45, 40, 3):
+        eng.run(n)
+    assert np.array_equal(eng.trace(L.TRACE_RA), a["ra"]) and np.array_equal(eng.trace(L.TRACE_LOGLIKE), a["ll"])
+    assert np.array_equal(eng.item_trace(), a["item"])
