@@ -131,3 +131,39 @@ def test_metrics_over_replications():
     assert abs(m["Bias"]) < 1e-12 and abs(m["Rmse"] - np.sqrt(2 * 0.01 / 3)) < 1e-12 and abs(m["Corr"] - 1) < 1e-12
     m2 = pkg.getMetrics2(run, par="a")
     assert abs(m2["relativeBias"]) < 1e-12 and abs(m2["normalizedRmse"] - np.sqrt(2 * 0.01 / 3) / (4.1 - 0.9)) < 1e-12
+
+
+def test_julia_shim_mirrors_the_header_structs():
+    """The Julia shim cannot be executed here (no Julia toolchain), so its ccall struct mirrors are checked statically: ErmConfig /
+    ErmState list exactly the fields of erm_config / erm_state in include/ertirt.h, in order and with matching widths, and every
+    entry point the shim ccalls is declared in the header."""
+    hdr = open(os.path.join(pu.ROOT, "include", "ertirt.h")).read()
+    jl = open(os.path.join(pu.ROOT, "extendedrtirtmodeling.jl_amd", "julia", "ExtendedRtIrtModelingAMD.jl")).read()
+
+    def c_fields(name):
+        body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} " + name + ";", hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ctype, names = decl.split(None, 1)
+            for n in names.split(","):
+                n = n.strip()
+                out.append((n.lstrip("*"), "ptr" if n.startswith("*") or ctype.endswith("*") else ctype))
+        return out
+
+    def jl_fields(name):
+        body = re.search(r"struct " + name + r"\b(.*?)\nend", jl, re.S).group(1)
+        body = re.sub(r"#.*", "", body)
+        return [(m.group(1), m.group(2)) for m in re.finditer(r"(\w+)::([\w{}]+)", body)]
+
+    width = {"int32_t": "Int32", "int64_t": "Int64", "double": "Float64", "uint64_t": "UInt64", "ptr": "Ptr{Float64}"}
+    for cname, jname in (("erm_config", "ErmConfig"), ("erm_state", "ErmState")):
+        cf, jf = c_fields(cname), jl_fields(jname)
+        assert [n for n, _ in cf] == [n for n, _ in jf], (cname, cf, jf)
+        assert [width[t] for _, t in cf] == [t for _, t in jf], cname
+    called = set(re.findall(r"ccall\(\(:(erm_\w+)", jl))
+    declared = set(re.findall(r"\b(erm_[a-z_]+)\s*\(", hdr))
+    assert called and called <= declared, called - declared
