@@ -18,7 +18,7 @@ module ExtendedRtIrtModelingAMD
 using LinearAlgebra, Random
 
 export sample!, GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCrossQr, GibbsRtIrtLatentQr, GibbsRtIrtQuantile, GibbsRtIrtNull, GibbsRtIrtCross,
-       GibbsRtIrtLatent, libertirt_path!
+       GibbsRtIrtLatent, essRhat, simulateData!, libertirt_path!
 
 const LIB = Ref{String}(get(ENV, "LIBERTIRT", "libertirt.so"))
 libertirt_path!(p::AbstractString) = (LIB[] = String(p))
@@ -112,7 +112,7 @@ end
 dense(x) = isempty(x) ? Float64[] : Array{Float64}(x)
 ptr(x::Array{Float64}) = isempty(x) ? Ptr{Float64}(C_NULL) : pointer(x)
 
-function engine!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool)
+function engine!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool; upload::Bool = true)
     key = (intercept, onepl, cov2one)
     M.handle != C_NULL && M.key == key && return M.handle
     M.handle != C_NULL && ccall((:erm_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), M.handle)
@@ -121,6 +121,10 @@ function engine!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool)
                     M.seed, M.device, M.precision, 1, 0, 0, 0, 0, 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:erm_create, LIB[]), Cint, (Ref{ErmConfig}, Ref{Ptr{Cvoid}}), cfg, h))
+    if !upload                                                  # the data set will be generated on the device (simulateData!)
+        M.handle, M.key = h[], key
+        return M.handle
+    end
     Y = Array{UInt8}(M.Data.Y)                                  # Matrix{Bool} from setData* or a 0/1 numeric matrix
     logT = modelid(M) == MODEL_MLIRT ? Float64[] : dense(M.Data.logT)
     X = (modelid(M) in (MODEL_CROSSQR, MODEL_CROSS, MODEL_NULL) || C.nFeat == 0) ? Float64[] : dense(M.Data.X)
@@ -186,6 +190,44 @@ function sample!(M::GibbsAMD; intercept = false, itemtype::Union{String} = "2pl"
     modelid(M) in (MODEL_CROSSQR, MODEL_CROSS) && (P.ρ = copy(bufs[9]))
     modelid(M) == MODEL_CROSSQR && (P.ν = reshape(copy(bufs[10]), N, J))
     modelid(M) == MODEL_LATENTQR && (P.ν = copy(bufs[10]))
+    return M
+end
+
+"""
+    essRhat(MCMC, which) -> (ess, rhat)
+
+Effective sample size and split R-hat of every column of `Post.ra` (`which = TRACE_RA`), `Post.rt` or `Post.qr`, computed on the device
+from the resident traces (what `checkConvergence`, src/SimTools.jl:419-443, obtains from MCMCChains on the host).  Call after `sample!`.
+"""
+function essRhat(M::GibbsAMD, which::Integer)
+    M.handle == C_NULL && error("run sample! first")
+    w = ccall((:erm_trace_width, LIB[]), Int64, (Ptr{Cvoid}, Cint), M.handle, which)
+    ess, rhat = zeros(w), zeros(w)
+    check(ccall((:erm_get_diagnostics, LIB[]), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}), M.handle, which, ess, rhat))
+    return ess, rhat
+end
+
+"""
+    simulateData!(MCMC, truePara; type="norm", seed=4321)
+
+`setData*` on the device (src/SimTools.jl:117-368): draws X, theta, zeta, Y, logT from `truePara` straight into the engine's buffers;
+`truePara.θ`, `truePara.ζ` receive the generated truth and `MCMC.Data` the data set.
+"""
+function simulateData!(M::GibbsAMD, truePara; type::String = "norm", seed = 4321)
+    h = engine!(M, false, false, !(M isa GibbsRtIrtLatentQr || M isa GibbsRtIrtLatent); upload = false)
+    arrs = state_arrays(truePara)
+    GC.@preserve arrs begin
+        check(ccall((:erm_simulate_data, LIB[]), Cint, (Ptr{Cvoid}, Ref{ErmState}, UInt64, Cint), h, ErmState(map(ptr, arrs)...), UInt64(seed),
+                    type == "norm" ? 0 : type == "tail" ? 1 : 2))
+    end
+    C = M.Cond
+    θ, ζ = zeros(C.nSubj), zeros(C.nSubj)
+    check(ccall((:erm_get_truth, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h, θ, ζ))
+    truePara.θ, truePara.ζ = θ, ζ
+    Y = Array{UInt8}(undef, C.nSubj, C.nItem); logT = zeros(C.nSubj, C.nItem); X = zeros(C.nSubj, max(C.nFeat, 1))
+    check(ccall((:erm_get_data, LIB[]), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}), h, Y, logT, X))
+    M.Data = (Y = Y, κ = Y .- 0.5, T = exp.(logT), logT = logT, X = X[:, 1:C.nFeat])
+    M.truePara = truePara
     return M
 end
 
