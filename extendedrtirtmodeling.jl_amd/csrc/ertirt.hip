@@ -227,7 +227,8 @@ template <typename real> struct Engine : EngineBase {
             if (need_lds <= 158 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
             grid_blocks *= 2;
         }
-        if (fused() && fused_lds() > 160 * 1024) {       // the tiny step's scratch does not fit next to the pass layout: keep the two-kernel schedule
+        if (getenv("ERM_NO_FUSE")) fuse_ok = false;                       // diagnostics: the two-kernel schedule (stand-alone tiny kernel)
+        if (!fuse_ok || (fused() && fused_lds() > 160 * 1024)) {       // the tiny step's scratch does not fit next to the pass layout (or ERM_NO_FUSE): keep the two-kernel schedule
             fuse_ok = false;
             rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
             for (int ph = 0; ph < 2; ++ph) lds_pass[ph] = pass_lds(ph, nWaves);
