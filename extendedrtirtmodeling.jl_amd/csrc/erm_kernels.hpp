@@ -230,8 +230,9 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
     // (a workgroup of fewer than 256 threads has no waves to spare: every thread takes items)
     const int ioff = nthreads >= 256 ? 128 : 0;
     const int nit = nthreads - ioff;
-    const int rt_off = (nit >= 2 * J) ? J : 0;
-    for (int j = tid - ioff; tid >= ioff && j < J; j += (rt_off ? 2 * J : nit)) {
+    const int Jw = (J + 63) & ~63;                          // the second thread of an item starts at a wave boundary: lanes of one wave in
+    const int rt_off = (nit >= 2 * Jw) ? Jw : 0;            // both roles would run the two chains one after the other
+    for (int j = tid - ioff; tid >= ioff && j < J; j += (rt_off ? 2 * Jw : nit)) {
         if (STEP == 0) {
             const double S0 = st0[0 * J + j], S1 = st0[1 * J + j], S2 = st0[2 * J + j], K1 = st0[3 * J + j];
             double a = par[j], b = par[J + j];
@@ -263,7 +264,7 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
             par[j] = a; par[J + j] = b;
         }
     }
-    for (int j = tid - ioff - rt_off; tid >= ioff + rt_off && j < J; j += (rt_off ? 2 * J : nit)) {
+    for (int j = tid - ioff - rt_off; tid >= ioff + rt_off && j < J; j += (rt_off ? 2 * Jw : nit)) {
         if ((fam_rt(MODEL) || fam_lq(MODEL)) && STEP == 0) {
             // lambda: drawItemIntensity src/Draw.pl.jl:215-220 ; sig2t: drawItemTimeResidual :257-262
             // sum zeta, sum zeta^2 over subjects (RtIrt: (x'zeta)[0] and zz; LatentQr: tracked explicitly)
