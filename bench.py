@@ -156,7 +156,7 @@ def main():
     coll_dev = "cpu" if rehearse else None
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ERM_BENCH_FORCE_DIST") == "1":     # FORCE_DIST: exercise the RCCL calls with one rank on a one-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:     # ERM_BENCH_REHEARSE=1: the N>1 code path on a ONE-GPU box -- every rank on cuda:0, collectives over gloo on the CPU
