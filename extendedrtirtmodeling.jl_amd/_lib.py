@@ -22,6 +22,7 @@ EXPORTS = [
     "erm_create", "erm_destroy", "erm_set_data", "erm_set_state", "erm_get_state", "erm_run", "erm_rows_done",
     "erm_reset_trace", "erm_trace_width", "erm_get_trace", "erm_item_trace_width", "erm_get_item_trace", "erm_get_mean",
     "erm_post_count", "erm_get_diagnostics", "erm_simulate_data", "erm_get_truth", "erm_get_data", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample", "erm_sample_gig",
+    "erm_set_shard", "erm_copy",
 ]
 
 
@@ -54,6 +55,9 @@ class erm_timing(C.Structure):
         ("cu_count", C.c_int32), ("reserved", C.c_int32),
     ]
 
+
+# int (*erm_exchange_fn)(void* user, const void* dev_send, void* dev_recv, size_t bytes_per_rank)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 _lib = None
 
@@ -96,6 +100,8 @@ def load():
     lib.erm_debug_sample.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
     lib.erm_sample_gig.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.erm_set_shard.argtypes = [H, C.c_int, C.c_int, C.c_int64, C.c_int64, EXCHANGE_FN, C.c_void_p]
+    lib.erm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
     return lib
 
@@ -148,6 +154,23 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_shard(self, rank: int, count: int, n_subj_total: int, row_base: int, exchange):
+        """Make this engine one shard of a subject-sharded chain (include/ertirt.h, erm_set_shard).  `exchange(send_ptr, recv_ptr,
+        nbytes)` is the all-gather over the shards (see parallel.TorchExchange / parallel.ThreadExchange); an exception it raises
+        is kept in `self.exchange_error` and surfaces as an ErmError from the call that triggered the exchange."""
+        self.exchange_error = None
+
+        def _cb(user, send, recv, nbytes):
+            try:
+                exchange(send, recv, int(nbytes))
+                return 0
+            except BaseException as e:      # never let an exception cross the C frames
+                self.exchange_error = e
+                return -1
+
+        self._exchange_cb = EXCHANGE_FN(_cb)       # kept alive as long as the engine
+        check(self._lib.erm_set_shard(self._h, rank, count, n_subj_total, row_base, self._exchange_cb, None))
 
     # ---- data / state
     def set_data(self, Y, logT=None, X=None):

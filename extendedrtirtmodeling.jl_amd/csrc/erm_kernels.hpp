@@ -81,6 +81,8 @@ template <typename real> struct PassArgs {
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // diagnostics only: skip everything after stage k (0 = run everything)
     unsigned long long* dbg_ts;   // diagnostics only (ERM_TIMELINE): [2 workgroups][16 waves][16 checkpoints] of the 100 MHz wall clock
+    uint32_t row_base;    // subject index of local row 0 in the whole data set (subject-sharded chains; 0 otherwise): the random streams are
+                          // addressed by the GLOBAL subject index, so a chain does not depend on how its subjects are spread over devices
 };
 
 // Lanes of ONE wave exchange data through LDS: DS instructions of a wave execute in order, so a compiler-level fence is all
@@ -820,7 +822,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             const real sA = sh_rs[3 * li], sB = sh_rs[3 * li + 1], sC = sh_rs[3 * li + 2];
             // one Philox block per subject and sweep feeds both row draws: words 0,1 -> theta's normal, words 2,3 -> zeta's
             uint32_t rw0, rw1, rw2, rw3;
-            philox4x32_10((uint32_t)i, 0u, sweep, ((uint32_t)SITE_THETA << 24) | ((A.chain & 0xFFu) << 16), (uint32_t)A.seed, (uint32_t)(A.seed >> 32), rw0, rw1, rw2, rw3);
+            philox4x32_10((uint32_t)i + A.row_base, 0u, sweep, ((uint32_t)SITE_THETA << 24) | ((A.chain & 0xFFu) << 16), (uint32_t)A.seed, (uint32_t)(A.seed >> 32), rw0, rw1, rw2, rw3);
             if (PHASE == 0) {
                 // theta: src/Draw.pl.jl:49-62 (prior x*beta[:,1]) / :67-80 (Null prior)
                 const real mu0 = (MODEL == MLIRT || MODEL == RTIRT) ? mu0a : real(0);
@@ -883,7 +885,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             const real den = r_sqrt(sig22 * k2);
             const real parA = r_div(r_abs(ze - xb5), den);
             const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
-            Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, 0u, sweep + 1u);
+            Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i + A.row_base, 0u, sweep + 1u);
             nu_next = qr_weight<real>(st, parA, parB);
             if (rok) A.nu[i] = nu_next;
         }
@@ -937,7 +939,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
             ++n_trip; n_att += active ? 1u : 0u;
             if (active) {
                 uint32_t w0, w1, w2, w3;
-                philox4x32_10((uint32_t)(ra + rr), (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                philox4x32_10((uint32_t)(ra + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
                 real w;
                 const bool acc_ = pg1_attempt(z, w0, w1, w2, w3, w);
                 if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
@@ -1086,7 +1088,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(Pa
                     const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
                     real nun = real(1);
                     if constexpr (has_nu(MODEL)) {
-                        Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i, (uint32_t)j, sweep + 1u);
+                        Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i + A.row_base, (uint32_t)j, sweep + 1u);
                         nun = qr_weight<real>(st, parA, parB);
                         A.nu[e] = nun;
                     }
@@ -1216,6 +1218,13 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
 // A parameter that never moves (beta[1] = 0, Sigma_p[1,1] = 1 ...) has W = 0 and gets NaN, as MCMCChains reports it.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int DIAG_MAXSEQ = 32;
+// Subject-sharded chains: a device's reduced statistics (the nb group rows of a pass) summed into ONE row, the unit the devices
+// all-gather before every tiny step; reduce_rows order, so the result does not depend on the launch geometry of this kernel
+__global__ void __launch_bounds__(256) shard_pack_kernel(const double* gslab, int nb, int NS, double* out)
+{
+    reduce_rows(gslab, nb, NS, out, (int)threadIdx.x, (int)blockDim.x);
+}
+
 template <typename T>
 __global__ void diag_kernel(const T* tr, long long ncol, long long ld, int nIter, int nChain, int nBurnin, double* ess, double* rhat)
 {

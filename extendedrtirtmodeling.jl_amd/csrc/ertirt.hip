@@ -57,6 +57,7 @@ struct EngineBase {
     virtual int get_data(uint8_t*, double*, double*) = 0;
     virtual int get_truth(double*, double*) = 0;
     virtual int reset_trace() = 0;
+    virtual int set_shard(int, int, int64_t, int64_t, erm_exchange_fn, void*) = 0;
     int64_t rows_done = 0;
     int64_t post_rows = 0;
     erm_timing timing{};
@@ -112,6 +113,12 @@ template <typename real> struct Engine : EngineBase {
     DevBuf dDbgTs;                                   // ERM_TIMELINE diagnostics
     int cur = 0;
     int n_groups = 1;
+    // subject sharding (erm_set_shard): this device holds subjects [row_base, row_base + N) of n_total
+    int shard_rank = 0, shard_count = 1;
+    int64_t n_total = 0, row_base = 0;
+    erm_exchange_fn exch = nullptr; void* exch_user = nullptr;
+    DevBuf dShardSend, dShardRecv[2];
+    bool sharded() const { return shard_count > 1 || exch != nullptr; }
     bool fuse_ok = true;                              // false when the fused kernel's LDS layout cannot fit (very long tests): two kernels per sweep then
     bool fused() const { return !m_cq() && fuse_ok; }  // single-pass models run the tiny step inside the row-pass kernel
     DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
@@ -342,6 +349,7 @@ template <typename real> struct Engine : EngineBase {
         if (!m_nu()) { a.k1 = 0.0; a.k2 = 1.0; }                                   // no quantile weights: nu == 1, k1 = 0, k2 = 1
         { const char* e = getenv("ERM_PASS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
         a.dbg_ts = dDbgTs.as<unsigned long long>();
+        a.row_base = (uint32_t)row_base;
         return a;
     }
     TinyArgs tiny_args(int mode, int first, bool fz = false) const {
@@ -358,6 +366,9 @@ template <typename real> struct Engine : EngineBase {
         t.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); t.k2 = 2.0 / (q * (1.0 - q));
         if (!m_nu()) { t.k1 = 0.0; t.k2 = 1.0; }
         t.nq = nq(); t.ngx = ngx();
+        if (sharded()) {     // the statistics rows of all devices, gathered after every row pass; N = the whole data set
+            t.slab0 = dShardRecv[0].as<double>(); t.slab1 = dShardRecv[1].as<double>(); t.nb0 = shard_count; t.nb1 = shard_count; t.N = n_total;
+        }
         { const char* e = getenv("ERM_TINY_STOP"); t.dbg_stop = e ? atoi(e) : 0; }
         return t;
     }
@@ -370,6 +381,42 @@ template <typename real> struct Engine : EngineBase {
         if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed], stream));
         hipLaunchKernelGGL((pass_kernel<MODEL, real, PHASE, false>), dim3(grid_blocks), dim3(block_threads), lds_pass[PHASE], stream, a, t);
         if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed + 1], stream)); ++n_pass_timed; }
+        if (sharded()) return shard_exchange(PHASE, a.gslab);
+        return 0;
+    }
+    // Subject-sharded chains: this device's statistics of the pass just enqueued -> one row -> all-gather over the devices
+    int shard_exchange(int phase, const double* gslab) {
+        hipLaunchKernelGGL(shard_pack_kernel, dim3(1), dim3(256), 0, stream, gslab, n_groups, ns[phase], dShardSend.as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        if (exch(exch_user, dShardSend.p, dShardRecv[phase].p, (size_t)ns[phase] * sizeof(double)) != 0)
+            return fail(ERM_ERR_STATE, "the shard exchange callback failed");
+        return 0;
+    }
+    // element-wise sum over the devices of a small host vector, in rank order on every device (data constants in erm_set_data)
+    int shard_allsum(std::vector<double>& v) {
+        if (!sharded()) return 0;
+        const size_t nb = v.size() * sizeof(double);
+        if (nb > dShardSend.bytes) return fail(ERM_ERR_STATE, "shard scratch too small");
+        HIPCHK(hipMemcpy(dShardSend.p, v.data(), nb, hipMemcpyHostToDevice));
+        if (exch(exch_user, dShardSend.p, dShardRecv[0].p, nb) != 0) return fail(ERM_ERR_STATE, "the shard exchange callback failed");
+        std::vector<double> all(v.size() * (size_t)shard_count);
+        HIPCHK(hipMemcpy(all.data(), dShardRecv[0].p, nb * (size_t)shard_count, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < v.size(); ++e) { double t = 0.0; for (int r = 0; r < shard_count; ++r) t += all[(size_t)r * v.size() + e]; v[e] = t; }
+        return 0;
+    }
+    int set_shard(int rank, int count, int64_t ntot, int64_t base, erm_exchange_fn fn, void* user) override {
+        if (has_data || rows_done > 0) return fail(ERM_ERR_STATE, "erm_set_shard must precede erm_set_data");
+        if (count < 1 || rank < 0 || rank >= count) return fail(ERM_ERR_ARG, "bad shard rank / count");
+        if (!fn) return fail(ERM_ERR_ARG, "exchange callback is NULL");
+        if (base < 0 || ntot < N || base + N > ntot) return fail(ERM_ERR_ARG, "local subjects must lie inside [0, n_subj_total)");
+        if (ntot >= (1LL << 32)) return fail(ERM_ERR_ARG, "n_subj_total must fit 32 bits");
+        HIPCHK(hipSetDevice(cfg.device));
+        const size_t width = (size_t)std::max(std::max(ns[0], ns[1]), 3 * J + PMAX * PMAX + 8);
+        if (int rc = dShardSend.alloc(width * sizeof(double))) return rc;
+        for (int k = 0; k < (m_cq() ? 2 : 1); ++k) { if (int rc = dShardRecv[k].alloc(width * (size_t)count * sizeof(double))) return rc; }
+        shard_rank = rank; shard_count = count; n_total = ntot; row_base = base; exch = fn; exch_user = user;
+        fuse_ok = false;      // the exchange sits between the row pass and the next tiny step: two kernels per sweep, no graph
         return 0;
     }
     // one whole sweep of a single-pass model: tiny step + row pass in one launch; reads buffers [cur], writes [1 - cur]
@@ -423,7 +470,7 @@ template <typename real> struct Engine : EngineBase {
         if constexpr (fam_cq(MODEL)) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
         int64_t k = 0;
         if (nsweeps > 0) { if (int rc = enqueue_sweep<MODEL>(true, false)) return rc; k = 1; }
-        const bool use_graph = !cfg.profile && getenv("ERM_NO_GRAPH") == nullptr;
+        const bool use_graph = !cfg.profile && !sharded() && getenv("ERM_NO_GRAPH") == nullptr;
         if (use_graph && nsweeps - k >= GRAPH_SWEEPS) {
             if (!graph_exec) { if (int rc = build_graph<MODEL>()) return rc; }
             for (; nsweeps - k >= GRAPH_SWEEPS; k += GRAPH_SWEEPS) HIPCHK(hipGraphLaunch(graph_exec, stream));
@@ -530,7 +577,10 @@ template <typename real> struct Engine : EngineBase {
         if (Fk > 0 && !X) return fail(ERM_ERR_ARG, "X is required when n_feat > 0");
         HIPCHK(hipSetDevice(cfg.device));
         const size_t NJ = (size_t)N * J;
+        const double Ntot = sharded() ? (double)n_total : (double)N;      // a shard's column sums are completed over the devices
+        const int pp = p();
         std::vector<double> cst(cst_size(J), 0.0);
+        std::vector<double> g1((size_t)2 * J + PMAX * PMAX, 0.0);         // K0 | column sums of logT | x'x : summed over the devices
         {   // Y -> row-major bytes; K0_j = sum_i kappa_ij  (kappa = Y - 0.5, src/Base.pl.jl:74)
             std::vector<uint8_t> yr(NJ);
             for (int j = 0; j < J; ++j) {
@@ -541,43 +591,54 @@ template <typename real> struct Engine : EngineBase {
                     yr[(size_t)i * J + j] = col[i];
                     k0 += (double)col[i] - 0.5;
                 }
-                cst[cst_off_k0(J) + j] = k0;
+                g1[j] = k0;
             }
             HIPCHK(hipMemcpy(dY.p, yr.data(), NJ, hipMemcpyHostToDevice));
         }
         if (is_rt()) {
-            // column-centred logT; mean/std(Data.logT) are the kwargs of drawItemIntensity (src/Draw.pl.jl:215)
-            std::vector<real> cr(NJ);
-            double tot = 0.0;
             for (int j = 0; j < J; ++j) {
                 const double* col = logT + (size_t)j * N;
                 double sm = 0.0;
                 for (int64_t i = 0; i < N; ++i) { if (!std::isfinite(col[i])) return fail(ERM_ERR_ARG, "logT must be finite"); sm += col[i]; }
-                tot += sm;
-                const double m = sm / (double)N;
+                g1[(size_t)J + j] = sm;
+            }
+        }
+        for (int u = 0; u < pp; ++u) for (int v = 0; v < pp; ++v) {     // x'x with x = [1 X]
+            double t = 0.0;
+            for (int64_t i = 0; i < N; ++i) {
+                const double xu = u == 0 ? 1.0 : X[(size_t)(u - 1) * N + i], xv = v == 0 ? 1.0 : X[(size_t)(v - 1) * N + i];
+                t += xu * xv;
+            }
+            g1[(size_t)2 * J + u + v * PMAX] = t;
+        }
+        if (int rc = shard_allsum(g1)) return rc;
+        for (int j = 0; j < J; ++j) cst[cst_off_k0(J) + j] = g1[j];
+        if (is_rt()) {
+            // column-centred logT; mean/std(Data.logT) are the kwargs of drawItemIntensity (src/Draw.pl.jl:215)
+            std::vector<real> cr(NJ);
+            std::vector<double> g2(J, 0.0);
+            double tot = 0.0;
+            for (int j = 0; j < J; ++j) {
+                const double* col = logT + (size_t)j * N;
+                tot += g1[(size_t)J + j];
+                const double m = g1[(size_t)J + j] / Ntot;
                 double sq = 0.0;
                 for (int64_t i = 0; i < N; ++i) { const double c = col[i] - m; sq += c * c; cr[(size_t)i * J + j] = (real)c; }
-                cst[cst_off_m(J) + j] = m; cst[cst_off_csq(J) + j] = sq;
+                cst[cst_off_m(J) + j] = m; g2[j] = sq;
             }
-            const double mu = tot / (double)NJ;
+            if (int rc = shard_allsum(g2)) return rc;
+            for (int j = 0; j < J; ++j) cst[cst_off_csq(J) + j] = g2[j];
+            const double mu = tot / (Ntot * (double)J);
             double ss = 0.0;
-            for (int j = 0; j < J; ++j) { const double dm = cst[cst_off_m(J) + j] - mu; ss += cst[cst_off_csq(J) + j] + (double)N * dm * dm; }
-            cst[cst_off_mu(J)] = mu; cst[cst_off_mu(J) + 1] = std::sqrt(ss / (double)(NJ - 1));
+            for (int j = 0; j < J; ++j) { const double dm = cst[cst_off_m(J) + j] - mu; ss += cst[cst_off_csq(J) + j] + Ntot * dm * dm; }
+            cst[cst_off_mu(J)] = mu; cst[cst_off_mu(J) + 1] = std::sqrt(ss / (Ntot * (double)J - 1.0));
             HIPCHK(hipMemcpy(dC.p, cr.data(), NJ * sizeof(real), hipMemcpyHostToDevice));
         }
-        {   // X -> row-major; x'x with x = [1 X]
-            const int pp = p();
-            std::vector<real> xr((size_t)N * std::max(Fk, 1));
-            for (int u = 0; u < pp; ++u) for (int v = 0; v < pp; ++v) {
-                double t = 0.0;
-                for (int64_t i = 0; i < N; ++i) {
-                    const double xu = u == 0 ? 1.0 : X[(size_t)(u - 1) * N + i], xv = v == 0 ? 1.0 : X[(size_t)(v - 1) * N + i];
-                    t += xu * xv;
-                }
-                cst[cst_off_xtx(J) + u + v * PMAX] = t;
-            }
+        {   // X -> row-major
+            for (int u = 0; u < pp; ++u) for (int v = 0; v < pp; ++v) cst[cst_off_xtx(J) + u + v * PMAX] = g1[(size_t)2 * J + u + v * PMAX];
             if (int rc = invert_xtx(cst)) return rc;
             if (Fk > 0) {
+                std::vector<real> xr((size_t)N * Fk);
                 for (int f = 0; f < Fk; ++f) for (int64_t i = 0; i < N; ++i) xr[(size_t)i * Fk + f] = (real)X[(size_t)f * N + i];
                 HIPCHK(hipMemcpy(dX.p, xr.data(), (size_t)N * Fk * sizeof(real), hipMemcpyHostToDevice));
             }
@@ -612,6 +673,7 @@ template <typename real> struct Engine : EngineBase {
     DevBuf dTruthTheta, dTruthZeta;
     std::vector<double> col_mean;      // column means of logT (kept for erm_get_data)
     int simulate_data(const erm_state* tr, uint64_t seed, int noise) override {
+        if (sharded()) return fail(ERM_ERR_STATE, "erm_simulate_data is not available on a shard");
         if (!tr || !tr->a || !tr->b) return fail(ERM_ERR_ARG, "truth needs a and b");
         if (is_rt() && (!tr->lambda || !tr->sig2t)) return fail(ERM_ERR_ARG, "truth needs lambda and sig2t for response-time models");
         if (noise < 0 || noise > 2) return fail(ERM_ERR_ARG, "noise must be 0 (norm), 1 (tail) or 2 (skew)");
@@ -1023,6 +1085,18 @@ int erm_get_data(erm_handle h, uint8_t* Y, double* logT, double* X) { CHK_H; ret
 int erm_get_truth(erm_handle h, double* theta, double* zeta) { CHK_H; return h->e->get_truth(theta, zeta); }
 int erm_get_diagnostics(erm_handle h, int which, double* ess, double* rhat) { CHK_H; if (!ess || !rhat) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_diagnostics(which, ess, rhat); }
 int erm_get_timing(erm_handle h, erm_timing* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); *out = h->e->timing; return 0; }
+int erm_set_shard(erm_handle h, int rank, int count, int64_t n_subj_total, int64_t row_base, erm_exchange_fn exchange, void* user)
+{
+    CHK_H;
+    return h->e->set_shard(rank, count, n_subj_total, row_base, exchange, user);
+}
+int erm_copy(void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (!dst || !src) return fail(ERM_ERR_ARG, "dst/src is NULL");
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    return 0;
+}
 const char* erm_last_error(void) { return g_err.c_str(); }
 const char* erm_version(void) { return "ertirt-amd 0.1.0 (gfx950)"; }
 

@@ -14,6 +14,7 @@
  */
 #ifndef ERTIRT_H
 #define ERTIRT_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -129,6 +130,24 @@ int64_t erm_post_count(erm_handle h);   /* number of rows that entered the means
 int erm_get_diagnostics(erm_handle h, int which, double* ess, double* rhat);
 
 int erm_get_timing(erm_handle h, erm_timing* out);
+/* Subject sharding of ONE chain over several devices (second bullet).  The reference has no counterpart: its
+ * conditionals (src/Draw.pl.jl:36-606) make subjects independent given the item / structural parameters, so each device keeps
+ * n_subj of the n_subj_total subjects (local row 0 is subject row_base), every device repeats the tiny step on identical inputs, and
+ * the only exchange is an all-gather of one row of sufficient statistics per row pass (stat width x 8 bytes per device) plus two
+ * all-gathers of column sums inside erm_set_data.  Random streams are addressed by the global subject index: a sharded chain equals
+ * the unsharded one up to the summation order of the statistics.
+ * `exchange` is the caller's all-gather: it must place device r's `bytes_per_rank` bytes from `dev_send` at
+ * dev_recv + r * bytes_per_rank on every device, return 0 when dev_recv is complete, non-zero on failure (erm_run then returns
+ * ERM_ERR_STATE).  Both pointers are device memory of this engine; the engine's stream is idle during the call.  The library itself
+ * stays free of any communication dependency: the host side plugs in RCCL (torch.distributed) or whatever moves the bytes.
+ * Call after erm_create and before erm_set_data, on every device with the same count / n_subj_total and disjoint row ranges.
+ * theta / zeta / nu in erm_state, the subject blocks of the traces and erm_get_mean cover the LOCAL subjects; item and structural
+ * entries are identical on all devices.  erm_simulate_data is not available on a shard. */
+typedef int (*erm_exchange_fn)(void* user, const void* dev_send, void* dev_recv, size_t bytes_per_rank);
+int erm_set_shard(erm_handle h, int rank, int count, int64_t n_subj_total, int64_t row_base, erm_exchange_fn exchange, void* user);
+/* hipMemcpy(dst, src, bytes, hipMemcpyDefault): lets a host-side exchange stage the buffers above without binding HIP itself. */
+int erm_copy(void* dst, const void* src, size_t bytes);
+
 const char* erm_last_error(void);
 const char* erm_version(void);
 
