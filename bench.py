@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--cpu-sweeps", type=int, default=-1, help="oracle sweeps for cpu_baseline (-1 = auto ~15 s, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket row-pass launches with HIP events")
+    ap.add_argument("--shard", action="store_true", help="NOT the headline: ONE chain of --nsubj subjects sharded over the ranks (strong scaling; "
+                                                        "one all-gather of a statistics row per row pass, SURVEY.md 8(e))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,13 +173,21 @@ def main():
     L = pkg._lib
     model, N, J, F = args.model, args.nsubj, args.nitem, args.nfeat
     Y, logT, X = make_data(pkg, model, N, J, F, seed=1234)
-    st = init_state(model, N, J, F, rank)
+    shard = args.shard and dist is not None
+    st = init_state(model, N, J, F, 0 if shard else rank)
     rows = args.warmup + args.steps
-    eng = L.Engine(model=getattr(L, "MODEL_" + model.upper()), n_item=J, n_subj=N, n_feat=0 if X is None else F, n_iter=rows, n_chain=1,
-                   n_burnin=args.warmup, cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, chain_id=rank, device=local_rank,
+    lo, n_loc = (0, N)
+    if shard:       # every rank builds the same data set and keeps its rows
+        lo, n_loc = pkg.parallel.shard_rows(N, world)[rank]
+        Y, logT, X = Y[lo:lo + n_loc], (None if logT is None else logT[lo:lo + n_loc]), (None if X is None else X[lo:lo + n_loc])
+        st = dict(st, **{k: st[k][lo:lo + n_loc] for k in ("theta", "zeta") if k in st})
+    eng = L.Engine(model=getattr(L, "MODEL_" + model.upper()), n_item=J, n_subj=n_loc, n_feat=0 if X is None else F, n_iter=rows, n_chain=1,
+                   n_burnin=args.warmup, cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, chain_id=0 if shard else rank, device=local_rank,
                    precision=L.PREC_F32 if args.precision == "f32" else L.PREC_F64,
                    trace_mode=L.TRACE_FULL if args.trace == "full" else L.TRACE_SUMMARY, lanes_per_row=args.lanes_per_row,
                    block_threads=args.block_threads, grid_blocks=args.grid_blocks, profile=0 if args.no_profile else 1)
+    if shard:
+        eng.set_shard(rank, world, N, lo, pkg.parallel.TorchExchange(L.load(), device=None if rehearse else f"cuda:{local_rank}"))
     eng.set_data(Y, logT, X)       # inputs resident in HBM from here on
     eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in st.items()})
 
@@ -201,7 +211,7 @@ def main():
 
     # posterior-summary gather over RCCL (outside the timed region; this is the only collective of the path)
     gather_ms = None
-    if dist is not None:
+    if dist is not None and not shard:
         mean = eng.get_mean()
         P = pkg.InputPara(theta=mean["theta"], a=mean["a"], b=mean["b"])
         for k_src, k_dst in (("zeta", "zeta"), ("lambda_", "lam"), ("sig2t", "sig2t"), ("beta", "beta"), ("sigp", "Sigp"), ("rho", "rho")):
@@ -215,23 +225,23 @@ def main():
 
     if rank == 0:
         cells = float(N) * J
-        value = cells * args.steps * world / dt
+        value = cells * args.steps * (1 if shard else world) / dt
         out = {
             "metric": "Gibbs cell-updates/s (nSubj x nItem x sweeps/s)", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"Gibbs{ {'mlirt': 'MlIrt', 'rtirt': 'RtIrt', 'latentqr': 'RtIrtLatentQr', 'crossqr': 'RtIrtCrossQr', 'null': 'RtIrtNull', 'cross': 'RtIrtCross', 'latent': 'RtIrtLatent'}[model] } "
-                                   f"nSubj={N} nItem={J} nFeat={F} nChain=1 per GPU (BASELINE.json configs[2])",
-                       "chains": world, "trace": args.trace, "lanes_per_row": tm["lanes_per_row"], "block_threads": tm["block_threads"],
+                                   f"nSubj={N} nItem={J} nFeat={F} " + (f"ONE chain, subjects sharded over {world} devices" if shard else "nChain=1 per GPU (BASELINE.json configs[2])"),
+                       "chains": 1 if shard else world, "subject_shards": world if shard else 1, "trace": args.trace, "lanes_per_row": tm["lanes_per_row"], "block_threads": tm["block_threads"],
                        "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"]},
-            "sweeps_per_s": args.steps * world / dt, "device_ms_per_step": tm["run_ms"] / args.steps,
+            "sweeps_per_s": args.steps * (1 if shard else world) / dt, "device_ms_per_step": tm["run_ms"] / args.steps,
         }
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
         if tm["pass_launches"] > 0:
             per_launch_s = tm["pass_ms_total"] / tm["pass_launches"] * 1e-3
             launches_per_sweep = 2 if model in ("crossqr", "cross") else 1
-            algo = ALGO_BYTES[model] * cells / launches_per_sweep
+            algo = ALGO_BYTES[model] * float(n_loc) * J / launches_per_sweep        # a launch covers this rank's subjects
             ach = algo / per_launch_s / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic_bytes(model, N, J, args), "kernel": "pass_kernel (one launch per sweep: tiny step + fused row pass; CrossQr: one of its two row passes)",

@@ -110,3 +110,45 @@ def test_shard_misuse_is_refused():
     assert isinstance(eng.exchange_error, RuntimeError)
     with pytest.raises(L.ErmError):
         eng.simulate_data(a=np.ones(5), b=np.zeros(5), lambda_=np.ones(5) * 3, sig2t=np.ones(5))
+
+
+# ------------------------------------------------------------------------------------------- two processes, one GPU, gloo
+def _proc_worker(rank, world, port, N, J, T, out):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    L = pkg._lib
+    Y, logT, X, init, _ = pu.make_problem("rtirt", N, J, 3, seed=7)
+    lo, n = pkg.parallel.shard_rows(N, world)[rank]
+    eng = L.Engine(model=MODELS["rtirt"], n_item=J, n_subj=n, n_feat=3, n_iter=T, n_chain=1, n_burnin=T // 2, cov2one=1, q_rt=0.85, seed=1234,
+                   precision=1, trace_mode=1, device=0)
+    eng.set_shard(rank, world, N, lo, pkg.parallel.TorchExchange(L.load(), device=None))       # gloo: the row is staged through the host
+    eng.set_data(Y[lo:lo + n], logT[lo:lo + n], X[lo:lo + n])
+    st = {("lambda_" if k == "lam" else k): v for k, v in init.items()}
+    st["theta"], st["zeta"] = st["theta"][lo:lo + n], st["zeta"][lo:lo + n]
+    eng.set_state(**st)
+    eng.run(T)
+    np.savez(out + f".{rank}.npz", ra=eng.trace(L.TRACE_RA)[:, :, 0], ll=eng.trace(L.TRACE_LOGLIKE)[:, 0, 0])
+    dist.destroy_process_group()
+
+
+def test_two_processes_share_one_chain_over_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    N, J, T = 500, 10, 5
+    out = str(tmp_path / "shard")
+    mp.spawn(_proc_worker, args=(2, port, N, J, T, out), nprocs=2, join=True)
+    Y, logT, X, init, _ = pu.make_problem("rtirt", N, J, 3, seed=7)
+    orc = pu.OracleProblem("rtirt", Y, logT, X, init, qRt=0.85, cov2one=True, seed=1234).run(T)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    np.testing.assert_array_equal(r0["ll"], r1["ll"])
+    ra = np.concatenate([r0["ra"][:, :250], r1["ra"][:, :250], r0["ra"][:, 250:]], axis=1)
+    assert pu.rel_err(ra, orc["ra"]).max() < 1e-8
+    assert pu.rel_err(r0["ll"], orc["ll"]).max() < 1e-8

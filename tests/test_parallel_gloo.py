@@ -64,3 +64,50 @@ def test_single_process_gather_is_identity():
     P = pkg.InputPara(theta=[1.0, 2.0], a=[0.5], b=[0.1], Sigp=np.eye(2))
     c = pkg.parallel.gather_posterior_summaries(P, 7, 3.5)
     assert c["count"] == 7 and np.allclose(c["theta"], [1, 2]) and np.allclose(c["Sigp"], [1, 0, 0, 1]) and c["loglike_sum"] == 3.5
+
+
+# ------------------------------------------------------------------------------------------- subject-sharded chains (erm_set_shard)
+class _HostCopy:
+    """Stands in for libertirt's erm_copy on a box without a GPU: the exchange only ever asks for byte copies."""
+
+    @staticmethod
+    def erm_copy(dst, src, nbytes):
+        import ctypes
+        ctypes.memmove(dst, src, nbytes)
+        return 0
+
+
+def _exchange_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = pu.ge.load_package()
+    ex = pkg.parallel.TorchExchange(_HostCopy, device=None)
+    got = []
+    for width in (7, 300, 7):                       # the statistics rows of different passes have different widths; buffers are reused
+        send = np.arange(width, dtype=np.float64) + 1000.0 * rank + width
+        recv = np.full(width * world, -1.0)
+        ex(send.ctypes.data, recv.ctypes.data, send.nbytes)
+        got.append(recv)
+    if rank == 1:
+        np.savez(out, *got)
+    dist.destroy_process_group()
+
+
+def test_two_rank_statistics_exchange(tmp_path):
+    out = str(tmp_path / "ex.npz")
+    mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    for k, width in enumerate((7, 300, 7)):
+        want = np.concatenate([np.arange(width) + 1000.0 * r + width for r in range(2)])
+        np.testing.assert_array_equal(got[f"arr_{k}"], want)
+
+
+def test_shard_rows_cover_the_subjects():
+    pkg = pu.ge.load_package()
+    for n, c in ((10, 3), (7, 7), (100000, 8), (5, 1)):
+        rows = pkg.parallel.shard_rows(n, c)
+        assert len(rows) == c and rows[0][0] == 0 and sum(k for _, k in rows) == n
+        assert all(rows[r][0] + rows[r][1] == rows[r + 1][0] for r in range(c - 1))
+        assert max(k for _, k in rows) - min(k for _, k in rows) <= 1
