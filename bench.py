@@ -134,8 +134,8 @@ def valu_profile(model, N, J, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--model", default="rtirt", choices=list(ALGO_BYTES))
     ap.add_argument("--nsubj", type=int, default=100000)
     ap.add_argument("--nitem", type=int, default=50)
@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--cpu-sweeps", type=int, default=-1, help="oracle sweeps for cpu_baseline (-1 = auto ~15 s, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket row-pass launches with HIP events")
+    ap.add_argument("--shard-exchange", default="rccl", choices=["rccl", "callback"], help="--shard: in-stream RCCL all-gather (default) or the "
+                                                        "host callback over torch.distributed")
     ap.add_argument("--shard", action="store_true", help="NOT the headline: ONE chain of --nsubj subjects sharded over the ranks (strong scaling; "
                                                         "one all-gather of a statistics row per row pass, SURVEY.md 8(e))")
     args = ap.parse_args()
@@ -186,8 +188,12 @@ def main():
                    precision=L.PREC_F32 if args.precision == "f32" else L.PREC_F64,
                    trace_mode=L.TRACE_FULL if args.trace == "full" else L.TRACE_SUMMARY, lanes_per_row=args.lanes_per_row,
                    block_threads=args.block_threads, grid_blocks=args.grid_blocks, profile=0 if args.no_profile else 1)
-    if shard:
+    if shard and (rehearse or args.shard_exchange == "callback"):
         eng.set_shard(rank, world, N, lo, pkg.parallel.TorchExchange(L.load(), device=None if rehearse else f"cuda:{local_rank}"))
+    elif shard:     # the library's own in-stream RCCL all-gather; the 128-byte id travels over the process group
+        box = [L.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.set_shard_rccl(rank, world, N, lo, box[0])
     eng.set_data(Y, logT, X)       # inputs resident in HBM from here on
     eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in st.items()})
 
@@ -232,7 +238,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"Gibbs{ {'mlirt': 'MlIrt', 'rtirt': 'RtIrt', 'latentqr': 'RtIrtLatentQr', 'crossqr': 'RtIrtCrossQr', 'null': 'RtIrtNull', 'cross': 'RtIrtCross', 'latent': 'RtIrtLatent'}[model] } "
                                    f"nSubj={N} nItem={J} nFeat={F} " + (f"ONE chain, subjects sharded over {world} devices" if shard else "nChain=1 per GPU (BASELINE.json configs[2])"),
-                       "chains": 1 if shard else world, "subject_shards": world if shard else 1, "trace": args.trace, "lanes_per_row": tm["lanes_per_row"], "block_threads": tm["block_threads"],
+                       "chains": 1 if shard else world, "subject_shards": world if shard else 1, "shard_exchange": (("callback" if rehearse else args.shard_exchange) if shard else None), "trace": args.trace, "lanes_per_row": tm["lanes_per_row"], "block_threads": tm["block_threads"],
                        "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"]},
             "sweeps_per_s": args.steps * (1 if shard else world) / dt, "device_ms_per_step": tm["run_ms"] / args.steps,
         }

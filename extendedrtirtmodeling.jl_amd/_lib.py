@@ -22,7 +22,7 @@ EXPORTS = [
     "erm_create", "erm_destroy", "erm_set_data", "erm_set_state", "erm_get_state", "erm_run", "erm_rows_done",
     "erm_reset_trace", "erm_trace_width", "erm_get_trace", "erm_item_trace_width", "erm_get_item_trace", "erm_get_mean",
     "erm_post_count", "erm_get_diagnostics", "erm_simulate_data", "erm_get_truth", "erm_get_data", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample", "erm_sample_gig",
-    "erm_set_shard", "erm_copy",
+    "erm_set_shard", "erm_copy", "erm_rccl_unique_id", "erm_set_shard_rccl",
 ]
 
 
@@ -102,6 +102,8 @@ def load():
     lib.erm_sample_gig.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p]
     lib.erm_set_shard.argtypes = [H, C.c_int, C.c_int, C.c_int64, C.c_int64, EXCHANGE_FN, C.c_void_p]
     lib.erm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.erm_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.erm_set_shard_rccl.argtypes = [H, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
     _lib = lib
     return lib
 
@@ -171,6 +173,14 @@ class Engine:
 
         self._exchange_cb = EXCHANGE_FN(_cb)       # kept alive as long as the engine
         check(self._lib.erm_set_shard(self._h, rank, count, n_subj_total, row_base, self._exchange_cb, None))
+
+    def set_shard_rccl(self, rank: int, count: int, n_subj_total: int, row_base: int, unique_id: bytes):
+        """Shard with the library's own in-stream RCCL all-gather (erm_set_shard_rccl); `unique_id`: the 128 bytes of rccl_unique_id()
+        made on one rank and handed to all of them."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of rccl_unique_id()")
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(self._lib.erm_set_shard_rccl(self._h, rank, count, n_subj_total, row_base, buf))
 
     # ---- data / state
     def set_data(self, Y, logT=None, X=None):
@@ -271,6 +281,12 @@ class Engine:
         t = erm_timing()
         check(self._lib.erm_get_timing(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in erm_timing._fields_}
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    check(load().erm_rccl_unique_id(buf))
+    return buf.raw
 
 
 def debug_sample(which, n, par0=None, par1=None, *, seed=1234, site=15, sweep=1, precision=PREC_F64, device=0):

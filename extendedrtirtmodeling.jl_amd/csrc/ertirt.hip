@@ -1,6 +1,8 @@
 // ertirt.hip -- C-ABI host implementation of libertirt.so (declared in include/ertirt.h).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I include ertirt.hip -o libertirt.so
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library is bound at run time (dlopen) and only by subject-sharded chains
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -25,6 +27,37 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (e__ != hipSuccess) {                                                                         \
             return fail(ERM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                \
         }                                                                                                \
+    } while (0)
+
+// RCCL, bound lazily: libertirt.so has no link-time communication dependency.  A process that already loaded RCCL (torch does)
+// gets that same copy back from dlopen by soname.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    int load() {
+        if (lib) return 0;
+        const char* env = getenv("ERM_RCCL_LIB");
+        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { if (n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; }
+        if (!lib) return fail(ERM_ERR_STATE, std::string("cannot load RCCL: ") + dlerror());
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString) { lib = nullptr; return fail(ERM_ERR_STATE, "RCCL library lacks an expected symbol"); }
+        return 0;
+    }
+};
+Rccl g_rccl;
+#define RCCLCHK(expr)                                                                                    \
+    do {                                                                                                 \
+        ncclResult_t r__ = (expr);                                                                       \
+        if (r__ != ncclSuccess) return fail(ERM_ERR_STATE, std::string(#expr) + ": " + g_rccl.GetErrorString(r__)); \
     } while (0)
 
 struct DevBuf {
@@ -57,7 +90,7 @@ struct EngineBase {
     virtual int get_data(uint8_t*, double*, double*) = 0;
     virtual int get_truth(double*, double*) = 0;
     virtual int reset_trace() = 0;
-    virtual int set_shard(int, int, int64_t, int64_t, erm_exchange_fn, void*) = 0;
+    virtual int set_shard(int, int, int64_t, int64_t, erm_exchange_fn, void*, const void*) = 0;
     int64_t rows_done = 0;
     int64_t post_rows = 0;
     erm_timing timing{};
@@ -116,15 +149,18 @@ template <typename real> struct Engine : EngineBase {
     // subject sharding (erm_set_shard): this device holds subjects [row_base, row_base + N) of n_total
     int shard_rank = 0, shard_count = 1;
     int64_t n_total = 0, row_base = 0;
-    erm_exchange_fn exch = nullptr; void* exch_user = nullptr;
+    erm_exchange_fn exch = nullptr; void* exch_user = nullptr;     // the caller's all-gather (host-synchronous) ...
+    ncclComm_t comm = nullptr;                                       // ... or RCCL enqueued on the engine's stream
     DevBuf dShardSend, dShardRecv[2];
-    bool sharded() const { return shard_count > 1 || exch != nullptr; }
+    bool sharded() const { return exch != nullptr || comm != nullptr; }
     bool fuse_ok = true;                              // false when the fused kernel's LDS layout cannot fit (very long tests): two kernels per sweep then
     bool fused() const { return !m_cq() && fuse_ok; }  // single-pass models run the tiny step inside the row-pass kernel
     DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
 
     ~Engine() override {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph_tail) (void)hipGraphExecDestroy(graph_tail);
+        if (comm) (void)g_rccl.CommDestroy(comm);
         for (auto e : pass_ev) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -388,9 +424,13 @@ template <typename real> struct Engine : EngineBase {
     int shard_exchange(int phase, const double* gslab) {
         hipLaunchKernelGGL(shard_pack_kernel, dim3(1), dim3(256), 0, stream, gslab, n_groups, ns[phase], dShardSend.as<double>());
         HIPCHK(hipGetLastError());
+        return gather_row(phase, (size_t)ns[phase]);
+    }
+    // all-gather of n doubles of dShardSend into dShardRecv[k]: in stream order over RCCL, or through the caller's callback
+    int gather_row(int k, size_t n) {
+        if (comm) { RCCLCHK(g_rccl.AllGather(dShardSend.p, dShardRecv[k].p, n, ncclDouble, comm, stream)); return 0; }
         HIPCHK(hipStreamSynchronize(stream));
-        if (exch(exch_user, dShardSend.p, dShardRecv[phase].p, (size_t)ns[phase] * sizeof(double)) != 0)
-            return fail(ERM_ERR_STATE, "the shard exchange callback failed");
+        if (exch(exch_user, dShardSend.p, dShardRecv[k].p, n * sizeof(double)) != 0) return fail(ERM_ERR_STATE, "the shard exchange callback failed");
         return 0;
     }
     // element-wise sum over the devices of a small host vector, in rank order on every device (data constants in erm_set_data)
@@ -398,25 +438,31 @@ template <typename real> struct Engine : EngineBase {
         if (!sharded()) return 0;
         const size_t nb = v.size() * sizeof(double);
         if (nb > dShardSend.bytes) return fail(ERM_ERR_STATE, "shard scratch too small");
-        HIPCHK(hipMemcpy(dShardSend.p, v.data(), nb, hipMemcpyHostToDevice));
-        if (exch(exch_user, dShardSend.p, dShardRecv[0].p, nb) != 0) return fail(ERM_ERR_STATE, "the shard exchange callback failed");
+        HIPCHK(hipMemcpyAsync(dShardSend.p, v.data(), nb, hipMemcpyHostToDevice, stream));
+        if (int rc = gather_row(0, v.size())) return rc;
+        HIPCHK(hipStreamSynchronize(stream));
         std::vector<double> all(v.size() * (size_t)shard_count);
         HIPCHK(hipMemcpy(all.data(), dShardRecv[0].p, nb * (size_t)shard_count, hipMemcpyDeviceToHost));
         for (size_t e = 0; e < v.size(); ++e) { double t = 0.0; for (int r = 0; r < shard_count; ++r) t += all[(size_t)r * v.size() + e]; v[e] = t; }
         return 0;
     }
-    int set_shard(int rank, int count, int64_t ntot, int64_t base, erm_exchange_fn fn, void* user) override {
-        if (has_data || rows_done > 0) return fail(ERM_ERR_STATE, "erm_set_shard must precede erm_set_data");
+    int set_shard(int rank, int count, int64_t ntot, int64_t base, erm_exchange_fn fn, void* user, const void* rccl_id) override {
+        if (has_data || rows_done > 0 || sharded()) return fail(ERM_ERR_STATE, "erm_set_shard must precede erm_set_data and be called once");
         if (count < 1 || rank < 0 || rank >= count) return fail(ERM_ERR_ARG, "bad shard rank / count");
-        if (!fn) return fail(ERM_ERR_ARG, "exchange callback is NULL");
+        if (!fn && !rccl_id) return fail(ERM_ERR_ARG, "exchange callback / RCCL id is NULL");
         if (base < 0 || ntot < N || base + N > ntot) return fail(ERM_ERR_ARG, "local subjects must lie inside [0, n_subj_total)");
         if (ntot >= (1LL << 32)) return fail(ERM_ERR_ARG, "n_subj_total must fit 32 bits");
         HIPCHK(hipSetDevice(cfg.device));
         const size_t width = (size_t)std::max(std::max(ns[0], ns[1]), 3 * J + PMAX * PMAX + 8);
         if (int rc = dShardSend.alloc(width * sizeof(double))) return rc;
         for (int k = 0; k < (m_cq() ? 2 : 1); ++k) { if (int rc = dShardRecv[k].alloc(width * (size_t)count * sizeof(double))) return rc; }
+        if (rccl_id) {
+            if (int rc = g_rccl.load()) return rc;
+            ncclUniqueId id;
+            std::memcpy(&id, rccl_id, sizeof(id));
+            RCCLCHK(g_rccl.CommInitRank(&comm, count, id, rank));
+        }
         shard_rank = rank; shard_count = count; n_total = ntot; row_base = base; exch = fn; exch_user = user;
-        fuse_ok = false;      // the exchange sits between the row pass and the next tiny step: two kernels per sweep, no graph
         return 0;
     }
     // one whole sweep of a single-pass model: tiny step + row pass in one launch; reads buffers [cur], writes [1 - cur]
@@ -428,6 +474,7 @@ template <typename real> struct Engine : EngineBase {
         hipLaunchKernelGGL((pass_kernel<MODEL, real, 0, true>), dim3(grid_blocks), dim3(block_threads), fused_lds(), stream, a, t);
         if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed + 1], stream)); ++n_pass_timed; }
         cur ^= 1;
+        if (sharded()) return shard_exchange(0, a.gslab);     // a.gslab: the group rows this launch wrote
         return 0;
     }
     template <int MODEL, int STEP> int launch_tiny(int mode, int first) {
@@ -441,7 +488,9 @@ template <typename real> struct Engine : EngineBase {
     // removes the per-launch host overhead that otherwise leaves the GPU idle between the short kernels.
     static constexpr int GRAPH_SWEEPS = 32;
     static constexpr int PROFILE_STRIDE = 8;
-    hipGraphExec_t graph_exec = nullptr;
+    static constexpr int TAIL_SWEEPS = 4;            // a second, short graph for the remainder of a run (both counts are even: buffer parity)
+    hipGraphExec_t graph_exec = nullptr, graph_tail = nullptr;
+    bool ev_calibrated = false; double ev_null_ms = 0.0;
     template <int MODEL> int enqueue_sweep(bool first, bool timed) {
         if constexpr (!fam_cq(MODEL)) { if (fused()) return launch_fused<MODEL>(first, timed); }
         if (int rc = launch_tiny<MODEL, 0>(0, first)) return rc;
@@ -452,15 +501,15 @@ template <typename real> struct Engine : EngineBase {
         }
         return 0;
     }
-    template <int MODEL> int build_graph() {
+    template <int MODEL> int build_graph(int nsw, hipGraphExec_t* out) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         int rc = 0;
-        for (int k = 0; k < GRAPH_SWEEPS && !rc; ++k) rc = enqueue_sweep<MODEL>(false, false);
+        for (int k = 0; k < nsw && !rc; ++k) rc = enqueue_sweep<MODEL>(false, false);
         hipError_t e = hipStreamEndCapture(stream, &g);
         if (rc) return rc;
         HIPCHK(e);
-        HIPCHK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
+        HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
         HIPCHK(hipGraphDestroy(g));
         return 0;
     }
@@ -470,14 +519,31 @@ template <typename real> struct Engine : EngineBase {
         if constexpr (fam_cq(MODEL)) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
         int64_t k = 0;
         if (nsweeps > 0) { if (int rc = enqueue_sweep<MODEL>(true, false)) return rc; k = 1; }
-        const bool use_graph = !cfg.profile && !sharded() && getenv("ERM_NO_GRAPH") == nullptr;
-        if (use_graph && nsweeps - k >= GRAPH_SWEEPS) {
-            if (!graph_exec) { if (int rc = build_graph<MODEL>()) return rc; }
-            for (; nsweeps - k >= GRAPH_SWEEPS; k += GRAPH_SWEEPS) HIPCHK(hipGraphLaunch(graph_exec, stream));
+        // (a callback exchange synchronises with the host once per pass and cannot be captured; RCCL's all-gather is a stream operation)
+        const bool use_graph = exch == nullptr && getenv("ERM_NO_GRAPH") == nullptr;
+        // profile mode brackets ONE sweep's row pass with events before every replayed block of GRAPH_SWEEPS sweeps (and every
+        // PROFILE_STRIDE-th sweep of the remainder): a live sample of the timed region whose bracketing overhead (~4.6 us per pair)
+        // stays negligible for the whole-job timing, while the bulk of the sweeps still runs from the graph
+        // (TWO single sweeps per block, the first one bracketed: a fused sweep flips the double buffers, and the graph must always be
+        // replayed with the buffer parity it was captured with)
+        const int64_t block = GRAPH_SWEEPS + (cfg.profile ? 2 : 0);
+        // (in profile mode the graph is built by the first run that sweeps at all -- a benchmark's warm-up -- so that capture and
+        // instantiation, a millisecond or two, never fall into a timed run)
+        if (use_graph && !graph_exec && k == 1 && (cfg.profile || nsweeps - k >= block)) {
+            if (int rc = build_graph<MODEL>(GRAPH_SWEEPS, &graph_exec)) return rc;
+            if (int rc = build_graph<MODEL>(TAIL_SWEEPS, &graph_tail)) return rc;
         }
-        // profile mode brackets every PROFILE_STRIDE-th sweep's row pass with events: a live sample of the timed region whose
-        // bracketing overhead (~4.6 us per pair) stays negligible for the whole-job timing
-        for (; k < nsweeps; ++k) { if (int rc = enqueue_sweep<MODEL>(false, (k % PROFILE_STRIDE) == 0)) return rc; }
+        if (use_graph && nsweeps - k >= block) {
+            for (; nsweeps - k >= block; k += block) {
+                if (cfg.profile) {
+                    if (int rc = enqueue_sweep<MODEL>(false, true)) return rc;
+                    if (int rc = enqueue_sweep<MODEL>(false, false)) return rc;
+                }
+                HIPCHK(hipGraphLaunch(graph_exec, stream));
+            }
+        }
+        if (use_graph && graph_tail && k >= 1) { for (; nsweeps - k >= TAIL_SWEEPS; k += TAIL_SWEEPS) HIPCHK(hipGraphLaunch(graph_tail, stream)); }
+        for (int64_t r = 0; k < nsweeps; ++k, ++r) { if (int rc = enqueue_sweep<MODEL>(false, (r % PROFILE_STRIDE) == 0)) return rc; }
         if (int rc = launch_tiny<MODEL, 0>(1, nsweeps == 0)) return rc;
         return 0;
     }
@@ -496,7 +562,8 @@ template <typename real> struct Engine : EngineBase {
         for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpyAsync(dCtlB[k].p, &c, sizeof(Ctl), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(dGcnt.p, 0, dGcnt.bytes, stream));
         n_pass_timed = 0;
-        if (cfg.profile && pass_ev.size() >= 64) {   // empty event pairs: the bracketing overhead that is subtracted from every timed launch
+        const bool calibrate = cfg.profile && pass_ev.size() >= 64 && !ev_calibrated;
+        if (calibrate) {   // empty event pairs, once per engine: the bracketing overhead that is subtracted from every timed launch
             for (int k = 0; k < 16; ++k) { HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 2 - 2 * k], stream)); HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 1 - 2 * k], stream)); }
         }
         HIPCHK(hipEventRecord(ev0, stream));
@@ -507,11 +574,12 @@ template <typename real> struct Engine : EngineBase {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
         timing.run_ms = ms; timing.sweeps = nsweeps; timing.pass_ms_total = 0.0; timing.pass_launches = n_pass_timed;
-        double null_ms = 0.0;
-        if (cfg.profile && pass_ev.size() >= 64) {
-            for (int k = 0; k < 16; ++k) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, pass_ev[pass_ev.size() - 2 - 2 * k], pass_ev[pass_ev.size() - 1 - 2 * k])); null_ms += t; }
-            null_ms /= 16.0;
+        if (calibrate) {
+            double t16 = 0.0;
+            for (int k = 0; k < 16; ++k) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, pass_ev[pass_ev.size() - 2 - 2 * k], pass_ev[pass_ev.size() - 1 - 2 * k])); t16 += t; }
+            ev_null_ms = t16 / 16.0; ev_calibrated = true;
         }
+        const double null_ms = ev_null_ms;
         timing.event_overhead_ms = null_ms;
         for (int64_t k = 0; k < n_pass_timed; ++k) {
             float t = 0.f;
@@ -1088,7 +1156,23 @@ int erm_get_timing(erm_handle h, erm_timing* out) { CHK_H; if (!out) return fail
 int erm_set_shard(erm_handle h, int rank, int count, int64_t n_subj_total, int64_t row_base, erm_exchange_fn exchange, void* user)
 {
     CHK_H;
-    return h->e->set_shard(rank, count, n_subj_total, row_base, exchange, user);
+    if (!exchange) return fail(ERM_ERR_ARG, "exchange callback is NULL");
+    return h->e->set_shard(rank, count, n_subj_total, row_base, exchange, user, nullptr);
+}
+int erm_rccl_unique_id(void* out128)
+{
+    if (!out128) return fail(ERM_ERR_ARG, "out is NULL");
+    if (int rc = g_rccl.load()) return rc;
+    ncclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    std::memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+int erm_set_shard_rccl(erm_handle h, int rank, int count, int64_t n_subj_total, int64_t row_base, const void* unique_id128)
+{
+    CHK_H;
+    if (!unique_id128) return fail(ERM_ERR_ARG, "unique id is NULL");
+    return h->e->set_shard(rank, count, n_subj_total, row_base, nullptr, nullptr, unique_id128);
 }
 int erm_copy(void* dst, const void* src, size_t bytes)
 {

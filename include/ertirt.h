@@ -145,6 +145,12 @@ int erm_get_timing(erm_handle h, erm_timing* out);
  * entries are identical on all devices.  erm_simulate_data is not available on a shard. */
 typedef int (*erm_exchange_fn)(void* user, const void* dev_send, void* dev_recv, size_t bytes_per_rank);
 int erm_set_shard(erm_handle h, int rank, int count, int64_t n_subj_total, int64_t row_base, erm_exchange_fn exchange, void* user);
+/* The same, with the all-gather enqueued by the library itself on the engine's stream over RCCL (xGMI): no host synchronisation per
+ * pass, the one-launch-per-sweep schedule and hipGraph replay stay in force.  RCCL is bound at run time (dlopen; ERM_RCCL_LIB
+ * overrides the name), so nothing changes for callers that never shard.  erm_rccl_unique_id fills the 128-byte ncclUniqueId on ONE
+ * process; the caller hands it to all ranks (any transport), then every rank calls erm_set_shard_rccl (collective: ncclCommInitRank). */
+int erm_rccl_unique_id(void* out128);
+int erm_set_shard_rccl(erm_handle h, int rank, int count, int64_t n_subj_total, int64_t row_base, const void* unique_id128);
 /* hipMemcpy(dst, src, bytes, hipMemcpyDefault): lets a host-side exchange stage the buffers above without binding HIP itself. */
 int erm_copy(void* dst, const void* src, size_t bytes);
 

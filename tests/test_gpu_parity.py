@@ -245,3 +245,7 @@ def test_graph_replay_and_continuation(model):
         eng.run(n)
     assert np.array_equal(eng.trace(L.TRACE_RA), a["ra"]) and np.array_equal(eng.trace(L.TRACE_LOGLIKE), a["ll"])
     assert np.array_equal(eng.item_trace(), a["item"])
+    # profile mode (bench.py) interleaves event-bracketed single sweeps with the replayed blocks: same chain, and launches were timed
+    b = pu.run_device(model, Y, logT, X, init, 88, precision="f32", profile=1)
+    assert np.array_equal(b["ra"], a["ra"]) and np.array_equal(b["ll"], a["ll"]) and np.array_equal(b["item"], a["item"])
+    assert b["engine"].timing()["pass_launches"] >= 2

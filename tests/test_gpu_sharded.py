@@ -70,6 +70,26 @@ def test_one_shard_is_the_two_kernel_schedule():
     assert pu.max_rel_err(res) < 1e-8
 
 
+def test_single_rank_rccl_shard_with_graph_replay():
+    """erm_set_shard_rccl with a communicator of ONE rank (all a one-GPU box allows): the in-stream all-gather, the fused
+    one-launch sweep and hipGraph replay (40 sweeps > one 32-sweep graph) against the oracle."""
+    pkg = ge.load_package()
+    L = pkg._lib
+    N, J, T = 300, 8, 40
+    Y, logT, X, init, _ = pu.make_problem("rtirt", N, J, 3, seed=7)
+    eng = L.Engine(model=MODELS["rtirt"], n_item=J, n_subj=N, n_feat=3, n_iter=T, n_chain=1, n_burnin=T // 2, cov2one=1, q_rt=0.85, seed=1234,
+                   precision=1, trace_mode=1)
+    eng.set_shard_rccl(0, 1, N, 0, L.rccl_unique_id())
+    eng.set_data(Y, logT, X)
+    eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in init.items()})
+    eng.run(T)
+    orc = pu.OracleProblem("rtirt", Y, logT, X, init, qRt=0.85, cov2one=True, seed=1234).run(T)
+    assert pu.rel_err(eng.trace(L.TRACE_RA)[:, :, 0], orc["ra"]).max() < 1e-7
+    assert pu.rel_err(eng.trace(L.TRACE_LOGLIKE)[:, 0, 0], orc["ll"]).max() < 1e-8
+    with pytest.raises(L.ErmError):
+        eng.set_shard_rccl(0, 1, N, 0, L.rccl_unique_id())          # once only, and never after the data
+
+
 def test_f32_shards_match_oracle_for_one_sweep():
     """Same criteria as test_gpu_parity.test_f32_one_sweep (absolute tolerances; a rare flipped PG decision moves a few rows)."""
     N = 3000
