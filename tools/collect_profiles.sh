@@ -9,8 +9,9 @@ set -e
 TAG=${1:-round1}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG; mkdir -p $OUT
+# 1. is the DEFAULT bench command (minus the CPU baselines); the counter passes serialise kernels, so they use a shorter run
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --cpu-sweeps 0 > $OUT/stats.log 2>&1
 BENCH="python3 bench.py --steps 200 --warmup 20 --cpu-sweeps 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH --no-profile > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH --no-profile > $OUT/write.log 2>&1
 ERM_TINY_STOP=1 ERM_PASS_STOP=5 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_cal -- $BENCH --no-profile > $OUT/fetch_cal.log 2>&1

@@ -3,8 +3,8 @@
 for N in 1000 10000 100000 500000 2000000; do
   for J in 15 50 100; do
     if [ $((N * J)) -gt 100000000 ]; then continue; fi
-    S=200; [ $N -ge 500000 ] && S=60
-    timeout -k 10 200 python bench.py --cpu-sweeps 0 --nsubj $N --nitem $J --steps $S --warmup 10 --trace summary > gpurun_out/sz.json 2>/dev/null
+    S=1000; [ $N -ge 500000 ] && S=200
+    timeout -k 10 200 python bench.py --cpu-sweeps 0 --nsubj $N --nitem $J --steps $S --warmup 50 --trace summary > gpurun_out/sz.json 2>/dev/null
     python3 - <<PY
 import json
 d=json.loads(open("gpurun_out/sz.json").read().strip().splitlines()[-1])

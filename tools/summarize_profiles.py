@@ -57,7 +57,7 @@ tj[key] = {"valu": valu, "traffic_bytes_per_launch": traffic, "fetch_size_kb_raw
            "calibration": f"row-sum phase alone (ERM_PASS_STOP=5) reads {known:.0f} KB and reports FETCH_SIZE {cal:.0f} KB", "source": f"profiles/{tag}_*"}
 json.dump(tj, open(tj_path, "w"), indent=1)
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary ({tag})\n\ncommand: `python3 bench.py --steps 200 --warmup 20 --cpu-sweeps 0`\n\n")
+    f.write(f"# rocprofv3 summary ({tag})\n\ncommand: `python3 bench.py --cpu-sweeps 0` (the default workload and step counts; counter passes: `--steps 200 --warmup 20 --no-profile`)\n\n")
     f.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for r in rows[:4]:
         f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |\n")
