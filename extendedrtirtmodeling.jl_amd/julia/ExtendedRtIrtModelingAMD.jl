@@ -18,10 +18,12 @@ module ExtendedRtIrtModelingAMD
 using LinearAlgebra, Random
 
 export sample!, GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCrossQr, GibbsRtIrtLatentQr, GibbsRtIrtQuantile, GibbsRtIrtNull, GibbsRtIrtCross,
-       GibbsRtIrtLatent, essRhat, simulateData!, libertirt_path!
+       GibbsRtIrtLatent, essRhat, simulateData!, libertirt_path!, rcclUniqueId
 
 const LIB = Ref{String}(get(ENV, "LIBERTIRT", "libertirt.so"))
 libertirt_path!(p::AbstractString) = (LIB[] = String(p))
+# the 128-byte ncclUniqueId of a subject-sharded chain: made on ONE process, handed to all of them (MPI.Bcast!, a file, ...)
+rcclUniqueId() = (u = zeros(UInt8, 128); check(ccall((:erm_rccl_unique_id, LIB[]), Cint, (Ptr{UInt8},), u)); u)
 
 # ---- mirror of erm_config / erm_state / erm_timing (include/ertirt.h); field order and types must match exactly
 struct ErmConfig
@@ -58,8 +60,9 @@ for (T, model) in ((:GibbsMlIrt, MODEL_MLIRT), (:GibbsRtIrt, MODEL_RTIRT), (:Gib
         mutable struct $T <: GibbsAMD
             Cond; Data; truePara; Para; Post
             handle::Ptr{Cvoid}; key::Any; seed::UInt64; device::Int32; precision::Int32
-            function $T(Cond; Data = [], truePara = [], Para = Float64[], Post = Float64[], seed = 1234, device = 0, precision = 0)
-                obj = new(Cond, Data, truePara, Para, Post, C_NULL, nothing, UInt64(seed), Int32(device), Int32(precision))
+            shard::Any      # nothing, or (rank, count, nSubjTotal, rowBase, uid): Cond.nSubj / Data then describe this process's subjects only
+            function $T(Cond; Data = [], truePara = [], Para = Float64[], Post = Float64[], seed = 1234, device = 0, precision = 0, shard = nothing)
+                obj = new(Cond, Data, truePara, Para, Post, C_NULL, nothing, UInt64(seed), Int32(device), Int32(precision), shard)
                 setInitialValues(obj)                      # always overwrites Para, as the reference's constructors do
                 obj.Post = OutputPost([], [], [], [], Float64[])
                 finalizer(o -> (o.handle != C_NULL && ccall((:erm_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), o.handle)), obj)
@@ -121,6 +124,11 @@ function engine!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool; uploa
                     M.seed, M.device, M.precision, 1, 0, 0, 0, 0, 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:erm_create, LIB[]), Cint, (Ref{ErmConfig}, Ref{Ptr{Cvoid}}), cfg, h))
+    if M.shard !== nothing       # one chain over several devices (include/ertirt.h, erm_set_shard_rccl): collective, before the data
+        rank, count, ntot, base, uid = M.shard
+        length(uid) == 128 || error("shard: uid must be the 128 bytes of rcclUniqueId()")
+        GC.@preserve uid check(ccall((:erm_set_shard_rccl, LIB[]), Cint, (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Ptr{UInt8}), h[], rank, count, ntot, base, uid))
+    end
     if !upload                                                  # the data set will be generated on the device (simulateData!)
         M.handle, M.key = h[], key
         return M.handle
