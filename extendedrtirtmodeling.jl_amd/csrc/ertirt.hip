@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -38,7 +39,9 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::mutex mu;
     int load() {
+        std::lock_guard<std::mutex> lock(mu);      // engines of several host threads may shard at the same time
         if (lib) return 0;
         const char* env = getenv("ERM_RCCL_LIB");
         const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
