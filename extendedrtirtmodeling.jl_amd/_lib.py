@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libertirt.so")
+LIB_PATH = os.environ.get("ERM_LIB_PATH") or os.path.join(_HERE, "libertirt.so")      # ERM_LIB_PATH: diagnostics (library build variants)
 
 MODEL_MLIRT, MODEL_RTIRT, MODEL_CROSSQR, MODEL_LATENTQR = 0, 1, 2, 3
 MODEL_NULL, MODEL_CROSS, MODEL_LATENT = 4, 5, 6          # the non-quantile variants

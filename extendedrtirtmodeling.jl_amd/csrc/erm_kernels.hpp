@@ -109,6 +109,9 @@ template <typename T> __device__ __forceinline__ T bfly_sum(T v, int lo, int hi)
 __device__ __forceinline__ float  log1pexp_r(float x)  { return fmaxf(x, 0.f) + r_log(1.f + r_exp(-fabsf(x))); }
 __device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
+#ifndef ERM_F32_THREADS
+#define ERM_F32_THREADS 1024     // threads per workgroup of the fp32 engine = the register budget the row-pass kernel is compiled for (128 VGPRs)
+#endif
 constexpr double LOG_2PI = 1.8378770664093454836;
 constexpr int GROUP = 16;  // workgroups whose slab rows are summed by the last of them to finish
 constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
@@ -592,7 +595,7 @@ __device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* pa
 // (T.par_out, T.ctl_out, traces).  Inputs and outputs are distinct (double-buffered) allocations, so a workgroup that starts late
 // never sees a half-updated block.  That removes one kernel boundary and the tiny kernel's cold start from every sweep.
 template <int MODEL, typename real, int PHASE, bool FUSED>
-__global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : 1024) pass_kernel(PassArgs<real> A, TinyArgs T)
+__global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pass_kernel(PassArgs<real> A, TinyArgs T)
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;

@@ -242,7 +242,7 @@ template <typename real> struct Engine : EngineBase {
         }
         logW = 0; while ((1 << logW) < W) ++logW;
         IPL = (J + W - 1) / W;
-        const int max_threads = sizeof(real) == 8 ? 512 : 1024;
+        const int max_threads = sizeof(real) == 8 ? 512 : ERM_F32_THREADS;
         block_threads = cfg.block_threads > 0 ? cfg.block_threads : max_threads;
         if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= 1024 (fp32) / 512 (fp64)");
         const int R = 64 / W;
