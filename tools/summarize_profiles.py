@@ -67,4 +67,18 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
     if valu:
         f.write(f"\nVALU: {valu['valu_insts_per_launch']:.3g} wave-instructions per launch = {valu['valu_insts_per_cell_update']:.0f} per cell-update; VALU busy "
                 f"{100*valu['valu_busy_frac']:.0f} % of the kernel's cycles (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32))\n")
+# the other samplers' kernel statistics (tools/collect_model_stats.sh), when collected
+rows_m = []
+for m in ("mlirt", "latentqr", "crossqr"):
+    fm = os.path.join(src, f"kernel_stats_{m}.csv")
+    if os.path.exists(fm):
+        shutil.copy(fm, os.path.join(dst, f"{tag}_kernel_stats_{m}.csv"))
+    fm = os.path.join(dst, f"{tag}_kernel_stats_{m}.csv")
+    if os.path.exists(fm):
+        rows_m += [(m, r) for r in list(csv.DictReader(open(fm)))[:4] if "erm::" in r["Name"]]
+if rows_m:
+    with open(os.path.join(dst, f"{tag}_summary.md"), "a") as f:
+        f.write("\n## Other samplers (same command with `--model`, `tools/collect_model_stats.sh`)\n\n| model | kernel | calls | avg us |\n|---|---|---|---|\n")
+        for m, r in rows_m:
+            f.write(f"| {m} | `{r['Name'][:60]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} |\n")
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())
