@@ -35,7 +35,7 @@ class _GibbsBase:
     _has_intercept = True
 
     def __init__(self, Cond: SimConditions, *, Data=None, truePara=None, Para=None, Post=None,
-                 seed=1234, device=0, precision="f32", trace="full", chain_id=0, **engine_opts):
+                 seed=1234, device=0, precision="f32", trace="full", chain_id=0, shard=None, **engine_opts):
         self.Cond = Cond
         self.Data = Data
         self.truePara = truePara
@@ -44,13 +44,38 @@ class _GibbsBase:
         self.precision = precision
         self.trace = trace
         self.chain_id = int(chain_id)
+        # shard = (rank, count, nSubjTotal, rowBase, transport): this process holds subjects [rowBase, rowBase + Cond.nSubj) of ONE chain
+        # spread over `count` devices (include/ertirt.h erm_set_shard*); transport = the 128-byte id of _lib.rccl_unique_id() (the
+        # library's in-stream RCCL all-gather) or a callable exchange(send_ptr, recv_ptr, nbytes) such as parallel.TorchExchange.
+        # Cond.nSubj, Data, Para.theta / zeta / nu and the subject blocks of Post then describe the local subjects only.
+        self.shard = shard
         self.engine_opts = dict(engine_opts)
         self._engine = None
         self._engine_key = None
         self._data_on_device = False
         self.Para = None
         self.setInitialValues()          # constructors always overwrite Para (src/GibbsRtIrt.pl.jl:100-102)
+        if shard is not None:
+            self._shard_initial_values()
         self.Post = _OutputPost()
+
+    def _shard_initial_values(self):
+        """Initial values of a shard = the UNSHARDED sampler's initial values restricted to the local subjects: the whole-data-set
+        state is generated (same seed on every rank, so item and structural entries agree bit for bit) and theta / zeta are cut."""
+        import dataclasses
+        rank, count, ntot, base, _ = self.shard
+        local = self.Cond
+        if not (0 <= base and base + local.nSubj <= ntot):
+            raise ValueError("shard: local subjects must lie inside [0, nSubjTotal)")
+        self.Cond = dataclasses.replace(local, nSubj=int(ntot))
+        try:
+            self.setInitialValues()
+        finally:
+            self.Cond = local
+        for f in ("theta", "zeta"):
+            v = getattr(self.Para, f)
+            if np.size(v) == ntot:
+                setattr(self.Para, f, np.ascontiguousarray(np.asarray(v)[base:base + local.nSubj]))
 
     # -- per-model hooks
     def setInitialValues(self):
@@ -89,6 +114,12 @@ class _GibbsBase:
                           seed=self.seed, chain_id=self.chain_id, device=self.device, precision=_PREC[self.precision],
                           trace_mode=_TRACE[self.trace], **self.engine_opts)
         self._engine, self._engine_key = eng, key
+        if self.shard is not None:
+            rank, count, ntot, base, transport = self.shard
+            if callable(transport):
+                eng.set_shard(rank, count, ntot, base, transport)
+            else:
+                eng.set_shard_rccl(rank, count, ntot, base, transport)
         if resident is not None:
             eng.set_data(*resident)
             return eng

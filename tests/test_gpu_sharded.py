@@ -172,3 +172,38 @@ def test_two_processes_share_one_chain_over_gloo(tmp_path):
     ra = np.concatenate([r0["ra"][:, :250], r1["ra"][:, :250], r0["ra"][:, 250:]], axis=1)
     assert pu.rel_err(ra, orc["ra"]).max() < 1e-8
     assert pu.rel_err(r0["ll"], orc["ll"]).max() < 1e-8
+
+
+def test_sampler_classes_shard_like_the_reference_surface():
+    """GibbsRtIrt(Cond; Data, shard=...) + sample!: two shards (host threads, ThreadExchange) fill Post exactly like the unsharded sampler
+    with the same seed -- item blocks, qr and logLike to 1e-8 (fp64), subject blocks concatenated."""
+    import threading
+    pkg = ge.load_package()
+    N, J, T = 240, 8, 6
+    Y, logT, X, _, _ = pu.make_problem("rtirt", N, J, 3, seed=7)
+    Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=3, nIter=T, nChain=1)
+    ref = pkg.sample_b(pkg.GibbsRtIrt(Cond, Data=pkg.InputData(Y=Y, T=np.exp(logT), X=X), seed=5, precision="f64"))
+    ex = pkg.parallel.ThreadExchange(pkg._lib.load(), 2)
+    rows = pkg.parallel.shard_rows(N, 2)
+    out, err = [None, None], [None, None]
+
+    def work(r):
+        try:
+            lo, n = rows[r]
+            C = pkg.setCond(nSubj=n, nItem=J, nFeat=3, nIter=T, nChain=1)
+            D = pkg.InputData(Y=Y[lo:lo + n], T=np.exp(logT[lo:lo + n]), X=X[lo:lo + n])
+            out[r] = pkg.sample_b(pkg.GibbsRtIrt(C, Data=D, seed=5, precision="f64", shard=(r, 2, N, lo, ex.for_rank(r))))
+        except BaseException as e:
+            err[r] = e
+            ex.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert err == [None, None], err
+    n0 = rows[0][1]
+    ra = np.concatenate([out[0].Post.ra[:, :n0], out[1].Post.ra[:, :N - n0], out[0].Post.ra[:, n0:]], axis=1)
+    assert pu.rel_err(ra[:, :, 0], ref.Post.ra[:, :, 0]).max() < 1e-8
+    assert pu.rel_err(out[0].Post.qr[:, :, 0], ref.Post.qr[:, :, 0]).max() < 1e-8
+    assert pu.rel_err(out[1].Post.logLike[:, 0, 0], ref.Post.logLike[:, 0, 0]).max() < 1e-8
+    np.testing.assert_array_equal(out[0].Post.mean.a, out[1].Post.mean.a)
