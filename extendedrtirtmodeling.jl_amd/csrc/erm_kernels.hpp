@@ -165,14 +165,48 @@ __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
 // across the lanes of ONE wave; all lanes of the wave must call it
 __device__ inline void chol_lower_wave(int n, const double* V, double* L, int lane)
 {
+    if (n <= 8) {
+        // the usual sizes (2 (nFeat + 1) = 8 for the default nFeat = 3): lane i keeps row i of L in registers and reads the pivot row by
+        // lane broadcast, so a column step costs no LDS round trips; same operations in the same order as the general loop below
+        double row[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) row[k] = 0.0;
+        const int li = lane < n ? lane : n - 1;
+        for (int jj = 0; jj < n; ++jj) {
+            double t = V[li + jj * n];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double bj = __shfl(row[k], jj, 64);
+                t = fma(-(k < jj ? row[k] : 0.0), bj, t);
+            }
+            const double piv = __shfl(t, jj, 64);
+            double r = __builtin_amdgcn_rsq(piv);
+            r = r * fma(-0.5 * piv * r, r, 1.5);
+            r = r * fma(-0.5 * piv * r, r, 1.5);
+            const double v = (lane >= jj && lane < n) ? t * r : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) row[k] = (k == jj) ? v : row[k];
+        }
+        if (lane < n) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k <= lane && k < n) L[lane + k * n] = row[k];
+        }
+        wave_sync();
+        return;
+    }
     for (int jj = 0; jj < n; ++jj) {
         double t = 0.0;
         if (lane >= jj && lane < n) {
             t = V[lane + jj * n];
             for (int k = 0; k < jj; ++k) t -= L[lane + k * n] * L[jj + k * n];
         }
-        const double d = sqrt(__shfl(t, jj, 64));
-        if (lane >= jj && lane < n) L[lane + jj * n] = (lane == jj) ? d : t / d;
+        // 1/sqrt(pivot) by the hardware estimate and two Newton steps (full double precision), then multiplications only: the square
+        // root and the division of the textbook column step are the longest links of this one-wave dependent chain
+        const double piv = __shfl(t, jj, 64);
+        double r = __builtin_amdgcn_rsq(piv);
+        r = r * fma(-0.5 * piv * r, r, 1.5);
+        r = r * fma(-0.5 * piv * r, r, 1.5);
+        if (lane >= jj && lane < n) L[lane + jj * n] = t * r;       // the diagonal: piv / sqrt(piv)
         wave_sync();
     }
 }
