@@ -693,8 +693,10 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pas
         if (writer && tid == 0 && !T.first && T.tr_ll) T.tr_ll[prev_row] = st0[NS0 - 1];    // log-likelihood of the sweep the last pass completed
         // item draws now; the structural chain (beta_t -> Sigma_p_t, ~7 us of dependent fp64 work on one wave) runs on wave 0 AFTER the
         // staging barrier below, concurrently with the other waves' row sums, which do not need it (see `sh_ready`)
-        tiny_items<MODEL, 0>(T, lp, st0, nullptr, part, work, sweep, lcst);
-        if (wave == 0) tiny_struct<MODEL, 0, 0>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);   // threads < 128 draw no items
+        // wave 0 starts the pre-barrier part of the structural chain at once (it is the longest strand of the head and needs nothing of
+        // this sweep's item draws); in workgroups of 256+ threads it owns no item threads and skips tiny_items altogether
+        if (wave == 0) tiny_struct<MODEL, 0, 0>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);
+        if (wave != 0 || nthr < 256) tiny_items<MODEL, 0>(T, lp, st0, nullptr, part, work, sweep, lcst);
         __syncthreads();
         if (A.dbg_stop == 31) return;
         parsrc = lp;
