@@ -697,6 +697,21 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pas
         // this sweep's item draws); in workgroups of 256+ threads it owns no item threads and skips tiny_items altogether
         if (wave == 0) tiny_struct<MODEL, 0, 0>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);
         if (wave != 0 || nthr < 256) tiny_items<MODEL, 0>(T, lp, st0, nullptr, part, work, sweep, lcst);
+        // every item thread stages what it has just drawn for the row pass (same thread mapping as tiny_items), so ONE barrier ends the head
+        {
+            const int ioff = nthr >= 256 ? 128 : 0, nit = nthr - ioff, Jw = (J + 63) & ~63, rt_off = (nit >= 2 * Jw) ? Jw : 0;
+            const int jstep = rt_off ? 2 * Jw : nit;
+            for (int j = tid - ioff; tid >= ioff && j < J; j += jstep) {
+                const double a = lp[j], b = lp[J + j];
+                sh_a[j] = (real)a; sh_b[j] = (real)b; sh_a2[j] = (real)(a * a); sh_a2b[j] = (real)(a * a * b); sh_rho[j] = (real)lp[4 * J + j];
+            }
+            for (int j = tid - ioff - rt_off; tid >= ioff + rt_off && j < J; j += jstep) {
+                const double lam = lp[2 * J + j], sg = lp[3 * J + j];
+                sh_lamc[j] = (real)(lam - lcst[cst_off_m(J) + j]); sh_isig[j] = (real)(1.0 / sg); sh_lsig[j] = (real)log(sg);
+            }
+            if (tid == 0) *reinterpret_cast<int*>(sh_struct + 5) = 0;       // sh_ready
+            for (int e = tid; e < nWaves * NG; e += nthr) sh_gacc[e] = 0.0;
+        }
         __syncthreads();
         if (A.dbg_stop == 31) return;
         parsrc = lp;
@@ -704,7 +719,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pas
     const bool post_burn = trow >= A.ctl->burn_rows;
     int* sh_ready = reinterpret_cast<int*>(sh_struct + 5);      // FUSED: set by wave 0 once sh_struct holds Sigma_p_t, beta_t, sum 1/sig2t
 
-    // ---- stage item parameters and structural scalars
+    // ---- stage item parameters and structural scalars (stand-alone row pass; a FUSED kernel has done it above)
+    if (!FUSED) {
     for (int j = threadIdx.x; j < J; j += blockDim.x) {
         const double a = parsrc[j], b = parsrc[J + j], lam = parsrc[2 * J + j], sg = parsrc[3 * J + j], rho = parsrc[4 * J + j];
         sh_a[j] = (real)a; sh_b[j] = (real)b; sh_a2[j] = (real)(a * a); sh_a2b[j] = (real)(a * a * b);
@@ -720,6 +736,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pas
     }
     for (int e = threadIdx.x; e < nWaves * NG; e += blockDim.x) sh_gacc[e] = 0.0;
     __syncthreads();
+    }
 
     stamp(2);
     if (A.dbg_stop == 32) return;
