@@ -96,7 +96,8 @@ __device__ __forceinline__ void wave_sync()
 
 template <typename real> __device__ __forceinline__ real row_normal(uint32_t wa, uint32_t wb)
 {
-    return r_sqrt(real(-2) * r_log(word_to_unif<real>(wa))) * r_cos2pi(word_to_unif<real>(wb));
+    if constexpr (sizeof(real) == 8) return fm::sqrt(-2.0 * fm::log(word_to_unif<double>(wa))) * cospi(2.0 * word_to_unif<double>(wb));
+    else return r_sqrt(real(-2) * r_log(word_to_unif<real>(wa))) * r_cos2pi(word_to_unif<real>(wb));
 }
 
 template <typename T> __device__ __forceinline__ T bfly_sum(T v, int lo, int hi)   // sum over lanes differing in bits [lo, hi)
@@ -111,6 +112,9 @@ __device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + lo
 
 #ifndef ERM_F32_THREADS
 #define ERM_F32_THREADS 1024     // threads per workgroup of the fp32 engine = the register budget the row-pass kernel is compiled for (128 VGPRs)
+#endif
+#ifndef ERM_F64_THREADS
+#define ERM_F64_THREADS 768      // fp64 engine: 12 waves per CU (3 per SIMD), 168 VGPRs each -- ONE workgroup per CU, like the fp32 engine
 #endif
 constexpr double LOG_2PI = 1.8378770664093454836;
 constexpr int GROUP = 16;  // workgroups whose slab rows are summed by the last of them to finish
@@ -629,7 +633,7 @@ __device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* pa
 // (T.par_out, T.ctl_out, traces).  Inputs and outputs are distinct (double-buffered) allocations, so a workgroup that starts late
 // never sees a half-updated block.  That removes one kernel boundary and the tiny kernel's cold start from every sweep.
 template <int MODEL, typename real, int PHASE, bool FUSED>
-__global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pass_kernel(PassArgs<real> A, TinyArgs T)
+__global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_THREADS) pass_kernel(PassArgs<real> A, TinyArgs T)
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
@@ -1097,6 +1101,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pas
             // the 4 cells of a batch are summed in `real` and enter the fp64 accumulators once per batch (fp64 VALU work is what bounds
             // this phase; a 4-term fp32 sum costs ~1 ulp of its terms' own rounding)
             real bs[NSTAT]; real bl = real(0);
+            // fp64: sum_u log(1 + e^{-|eta_u|}) of a batch = log prod_u (1 + e^{-|eta_u|}) -- one logarithm per four cells (each factor is in (1, 2])
+            [[maybe_unused]] double bprod = 1.0;
 #pragma unroll
             for (int q = 0; q < NSTAT; ++q) bs[q] = real(0);
 #pragma unroll
@@ -1114,7 +1120,11 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pas
                     if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) bs[4] += c * ze;
                     if (A.mode == 1) {
                         const real eta = a * (th - b);
-                        real t = (y ? eta : real(0)) - log1pexp_r(eta);
+                        real t;
+                        if constexpr (sizeof(real) == 8) {
+                            t = (y ? eta : 0.0) - (eta > 0.0 ? eta : 0.0);
+                            bprod *= 1.0 + fm::exp_neg(fabs(eta));
+                        } else t = (y ? eta : real(0)) - log1pexp_r(eta);
                         if (fam_rt(MODEL) || fam_lq(MODEL)) {
                             const real er = c + ze - lamc;
                             t += real(-0.5) * ((real)LOG_2PI + lsig + er * er * isig);
@@ -1155,6 +1165,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? 512 : ERM_F32_THREADS) pas
             }
 #pragma unroll
             for (int q = 0; q < NSTAT; ++q) S[q] += (double)bs[q];
+            if constexpr (sizeof(real) == 8 && PHASE == 0) { if (A.mode == 1) bl -= fm::log(bprod); }
             llc += (double)bl;
         }
         if (jv) {
@@ -1457,6 +1468,19 @@ __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uin
     case 7: { const real z = (real)par0[k]; v = (double)pg_tail_weight<real>(z, real(0.125) * Const<real>::PI * Const<real>::PI + real(0.5) * z * z); } break;
     case 8: v = (double)qr_weight<real>(st, (real)par0[k], (real)par1[k]); break;
     case 9: v = (double)ndtri((real)par0[k]); break;
+    case 11: v = fm::log(par0[k]); break;           // the cell path's fp64 elementary functions (erm_rng.hpp, namespace fm)
+    case 12: v = fm::exp_neg(par0[k]); break;
+    case 13: v = fm::sqrt(par0[k]); break;
+    case 14: v = fm::div(par0[k], par1[k]); break;
+    case 10: {     // PG(1, par0) through the reference form of the attempt (every decision in `real` arithmetic)
+        const real z = real(0.5) * r_abs((real)par0[k]);
+        real o = real(0);
+        for (int tries = 0; tries < MAX_TRIES; ++tries) {
+            const uint32_t w0 = st.next(), w1 = st.next(), w2 = st.next(), w3 = st.next();
+            if (pg1_attempt_ref<real>(z, w0, w1, w2, w3, o)) break;
+        }
+        v = (double)o;
+    } break;
     }
     out[k] = v;
 }

@@ -42,6 +42,66 @@ __device__ __forceinline__ double r_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float  r_cos2pi(float x)  { return __builtin_amdgcn_cosf(x); }     // v_cos_f32 takes revolutions
 __device__ __forceinline__ double r_cos2pi(double x) { return cospi(2.0 * x); }
 
+// ---- fp64 elementary functions for the cell path ---------------------------------------------------
+// The OCML routines are correctly-rounded-grade and guard every special case: log(double) is 98 VALU instructions (double-double
+// arithmetic), log1p 135, sqrt 22, exp 42.  The cell path calls them on arguments whose range it knows (uniforms in (0,1), products of
+// them, exponents in [0, 700]) and needs ~1e-15 relative accuracy, not the last bit: these forms take 33 / 10 / 19 instructions.
+namespace fm {
+__device__ __forceinline__ double rcp(double b)                   // 1/b, b normal and finite: hardware estimate + two Newton steps
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0); r = fma(r, e, r);
+    e = fma(-b, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double div(double a, double b)         // a/b to < 1 ulp for normal, finite operands and quotient
+{
+    const double r = rcp(b), q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double sqrt(double a)                  // a > 0 normal: rsq estimate, one coupled Newton step, two corrections
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    g = fma(fma(-g, g, a), h, g);
+    g = fma(fma(-g, g, a), h, g);
+    return g;
+}
+// log(x), x > 0 normal: x = m 2^e with m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), log m = 2 atanh(s) = 2s (1 + s^2/3 + s^4/5 + ...);
+// |s| <= 0.1716, so the series is cut after s^20/21 (2.3e-17)
+__device__ __forceinline__ double log(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);                    // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = __builtin_amdgcn_ldexp(m, lo ? 1 : 0); e -= lo ? 1 : 0;
+    const double f = m - 1.0;
+    const double s = div(f, 2.0 + f), z = s * s;
+    double P = 1.0 / 21.0;
+    P = fma(P, z, 1.0 / 19.0); P = fma(P, z, 1.0 / 17.0); P = fma(P, z, 1.0 / 15.0); P = fma(P, z, 1.0 / 13.0); P = fma(P, z, 1.0 / 11.0);
+    P = fma(P, z, 1.0 / 9.0); P = fma(P, z, 1.0 / 7.0); P = fma(P, z, 1.0 / 5.0); P = fma(P, z, 1.0 / 3.0);
+    const double s2 = s + s;
+    const double lm = fma(s2, P * z, s2);
+    return fma((double)e, 0.693147180559945309417, lm);
+}
+// e^{-a}, 0 <= a (-> 0 beyond 700): a = k ln2 + r, |r| <= ln2/2, Taylor series of e^{-r} to r^13/13! (4e-18), scaled by 2^-k
+__device__ __forceinline__ double exp_neg(double a)
+{
+    a = a < 700.0 ? a : 700.0;
+    const double k = __builtin_rint(a * 1.44269504088896340736);
+    double r = fma(-k, 0.693147180559945286227, a);               // ln2 = hi + lo with hi = double(ln2): the fma forms a - k hi exactly
+    r = fma(-k, 2.31904681384629955842e-17, r);
+    const double t = -r;
+    double P = 1.0 / 6227020800.0;
+    P = fma(P, t, 1.0 / 479001600.0); P = fma(P, t, 1.0 / 39916800.0); P = fma(P, t, 1.0 / 3628800.0); P = fma(P, t, 1.0 / 362880.0);
+    P = fma(P, t, 1.0 / 40320.0); P = fma(P, t, 1.0 / 5040.0); P = fma(P, t, 1.0 / 720.0); P = fma(P, t, 1.0 / 120.0); P = fma(P, t, 1.0 / 24.0);
+    P = fma(P, t, 1.0 / 6.0); P = fma(P, t, 0.5); P = fma(P, t, 1.0); P = fma(P, t, 1.0);
+    return __builtin_amdgcn_ldexp(P, -(int)k);
+}
+}  // namespace fm
+
 template <typename real> struct Const;
 template <> struct Const<float> {
     static constexpr float PI = 3.14159265358979323846f;
@@ -158,32 +218,57 @@ __device__ __forceinline__ float ndtri(float p)
     const float w = -r_log(4.0f * p * (1.0f - p));
     return 1.41421356237f * giles_erfinv_poly(w) * x;
 }
-// fp64: the same polynomial as a starting point, polished by three Newton steps on Phi(x) = q in the lower tail
+// fp64: Wichura's (1988) algorithm AS 241, routine PPND16 -- rational minimax approximations of degree 7/7 on three ranges, relative
+// error < 1e-16 -- evaluated directly: no iteration, one logarithm and one square root outside the central range.  (The oracle reaches
+// the same function by Newton steps on erfc, oracle/orc_rng.h::orc_ndtri; the two agree to a few ulp, which the parity tests check.)
+namespace as241 {
+// each range in two forms: numerator and denominator separately (the cell path folds the division into one it needs anyway), and their quotient
+__device__ __forceinline__ void central(double r, double& n, double& d)      // |p - 1/2| <= 0.425, r = 0.180625 - (p - 1/2)^2; n / d = Phi^-1(p) / (p - 1/2)
+{
+    n = 2.5090809287301226727e+3; d = 5.2264952788528545610e+3;
+    n = fma(n, r, 3.3430575583588128105e+4); d = fma(d, r, 2.8729085735721942674e+4);
+    n = fma(n, r, 6.7265770927008700853e+4); d = fma(d, r, 3.9307895800092710610e+4);
+    n = fma(n, r, 4.5921953931549871457e+4); d = fma(d, r, 2.1213794301586595867e+4);
+    n = fma(n, r, 1.3731693765509461125e+4); d = fma(d, r, 5.3941960214247511077e+3);
+    n = fma(n, r, 1.9715909503065514427e+3); d = fma(d, r, 6.8718700749205790830e+2);
+    n = fma(n, r, 1.3314166789178437745e+2); d = fma(d, r, 4.2313330701600911252e+1);
+    n = fma(n, r, 3.3871328727963666080e+0); d = fma(d, r, 1.0);
+}
+__device__ __forceinline__ void mid(double r, double& n, double& d)          // r = sqrt(-log(min(p, 1 - p))) <= 5; n / d = |Phi^-1(p)|
+{
+    r -= 1.6;
+    n = 7.74545014278341407640e-4; d = 1.05075007164441684324e-9;
+    n = fma(n, r, 2.27238449892691845833e-2); d = fma(d, r, 5.47593808499534494600e-4);
+    n = fma(n, r, 2.41780725177450611770e-1); d = fma(d, r, 1.51986665636164571966e-2);
+    n = fma(n, r, 1.27045825245236838258e+0); d = fma(d, r, 1.48103976427480074590e-1);
+    n = fma(n, r, 3.64784832476320460504e+0); d = fma(d, r, 6.89767334985100004550e-1);
+    n = fma(n, r, 5.76949722146069140550e+0); d = fma(d, r, 1.67638483018380384940e+0);
+    n = fma(n, r, 4.63033784615654529590e+0); d = fma(d, r, 2.05319162663775882187e+0);
+    n = fma(n, r, 1.42343711074968357734e+0); d = fma(d, r, 1.0);
+}
+__device__ __forceinline__ void far(double r, double& n, double& d)          // r > 5
+{
+    r -= 5.0;
+    n = 2.01033439929228813265e-7; d = 2.04426310338993978564e-15;
+    n = fma(n, r, 2.71155556874348757815e-5); d = fma(d, r, 1.42151175831644588870e-7);
+    n = fma(n, r, 1.24266094738807843860e-3); d = fma(d, r, 1.84631831751005468180e-5);
+    n = fma(n, r, 2.65321895265761230930e-2); d = fma(d, r, 7.86869131145613259100e-4);
+    n = fma(n, r, 2.96560571828504891230e-1); d = fma(d, r, 1.48753612908506148525e-2);
+    n = fma(n, r, 1.78482653991729133580e+0); d = fma(d, r, 1.36929880922735805310e-1);
+    n = fma(n, r, 5.46378491116411436990e+0); d = fma(d, r, 5.99832206555887937690e-1);
+    n = fma(n, r, 6.65790464350110377720e+0); d = fma(d, r, 1.0);
+}
+__device__ __forceinline__ double central(double r) { double n, d; central(r, n, d); return n / d; }
+__device__ __forceinline__ double mid(double r) { double n, d; mid(r, n, d); return n / d; }
+__device__ __forceinline__ double far(double r) { double n, d; far(r, n, d); return n / d; }
+}  // namespace as241
 __device__ __forceinline__ double ndtri(double p)
 {
-    const bool upper = p > 0.5;
-    const double q = upper ? 1.0 - p : p;
-    const double xx = 2.0 * q - 1.0;
-    double w = -log(4.0 * q * (1.0 - q)), pl;
-    if (w < 5.0) {
-        w -= 2.5;
-        pl = 2.81022636e-08; pl = 3.43273939e-07 + pl * w; pl = -3.5233877e-06 + pl * w; pl = -4.39150654e-06 + pl * w;
-        pl = 0.00021858087 + pl * w; pl = -0.00125372503 + pl * w; pl = -0.00417768164 + pl * w; pl = 0.246640727 + pl * w;
-        pl = 1.50140941 + pl * w;
-    } else {
-        w = sqrt(w) - 3.0;
-        pl = -0.000200214257; pl = 0.000100950558 + pl * w; pl = 0.00134934322 + pl * w; pl = -0.00367342844 + pl * w;
-        pl = 0.00573950773 + pl * w; pl = -0.0076224613 + pl * w; pl = 0.00943887047 + pl * w; pl = 1.00167406 + pl * w;
-        pl = 2.83297682 + pl * w;
-    }
-    double x = 1.41421356237309504880 * pl * xx;
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        const double cdf = 0.5 * erfc(-x * 0.70710678118654752440);
-        const double pdf = 0.3989422804014327 * exp(-0.5 * x * x);
-        x -= (cdf - q) / pdf;
-    }
-    return upper ? -x : x;
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) return q * as241::central(0.180625 - q * q);
+    const double r = sqrt(-log(q < 0.0 ? p : 1.0 - p));
+    const double v = r <= 5.0 ? as241::mid(r) : as241::far(r);
+    return q < 0.0 ? -v : v;
 }
 
 template <typename real> __device__ __forceinline__ real word_to_unif(uint32_t w);
@@ -205,8 +290,9 @@ template <typename real> __device__ __forceinline__ real pg_tail_weight(real z, 
     return r_div(p, p + qenv);
 }
 
+// Reference form of one attempt (the specification, statement by statement, in `real` arithmetic throughout).
 template <typename real>
-__device__ __forceinline__ bool pg1_attempt(real z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, real& out)
+__device__ __forceinline__ bool pg1_attempt_ref(real z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, real& out)
 {
     const real t = real(0.64);
     const real PI = Const<real>::PI;
@@ -300,6 +386,119 @@ __device__ __forceinline__ bool pg1_attempt(float z, uint32_t w0, uint32_t w1, u
         else       { S += rho; if (V > S) return false; }
     }
     return true;
+}
+
+// fp64 engine: the same attempt with its accept / reject DECISIONS filtered through fp32.  The four comparisons of an attempt (tail
+// or left piece; left piece kept; second inverse-Gaussian root / truncation at t; first term of the alternating series) are evaluated
+// with the hardware-rate fp32 instructions first.  Each comes with a guard band several times wider than the worst fp32 error of its two
+// sides (derivations in DESIGN.md 4b): outside the band the fp32 outcome IS the fp64 outcome; a lane inside a band (about 4 in 10^5
+// attempts), with z > 10, or with a quantile argument below 2^-22 (where Giles' polynomial is extrapolated) repeats the attempt through
+// pg1_attempt_ref<double>.  Only an ACCEPTED draw is then evaluated in fp64, and only its value: one log, one AS 241 quantile or
+// one division -- instead of three fp64 exponentials, a log and a quantile per attempt.  Decisions, and therefore which Philox block a
+// cell's draw comes from, are those of the reference form; the value differs from it by rounding only (tests: draw by draw against the
+// oracle, and against pg1_attempt_ref on 2^24 draws).
+//   the series needs no second term: rho_2 = 5 e^{6 e1} <= 3.6e-8 for every x an attempt can propose (e^{2 e1} <= 1.93e-3), less than
+//   the band on V <= S_1, so V > S_1 + band implies V > S_2 (reject) and V <= S_1 - band implies accept.
+__device__ __forceinline__ bool pg1_attempt(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double& out)
+{
+    const float t = 0.64f, PI = 3.14159265358979f;
+    const float zf = (float)z;
+    const float K = fmaf(0.5f * zf, zf, 0.125f * PI * PI);
+    const float rK = r_rcp(K);
+    const float p = (0.5f * PI) * rK * r_exp(-K * t);
+    const bool large = z >= 1.5625;                                  // decided in fp64, like the reference form
+    float q = 0.42259909466742100f;
+    if (__any(large)) q = large ? 2.0f * r_exp(-zf) : q;
+    const double u1d = word_to_unif<double>(w1);
+    const float u0 = word_to_unif<float>(w0), u1 = (float)u1d, u2 = word_to_unif<float>(w2), V = word_to_unif<float>(w3);   // u1 with RELATIVE accuracy: its log is used
+    // (a) tail piece iff u0 (p + q) < p
+    const float da = fmaf(u0, p + q, -p);
+    const bool tail = da < 0.0f;
+    bool unsure = !(fabsf(da) > fmaf(2e-5f, p, 5e-6f * q)) || !(z <= 10.0);
+    const float pin = large ? u1 : u1 * 0.10564977366685525f;
+    const float L = -r_log(tail ? u1 : 4.0f * pin * (1.0f - pin));
+    float wc = L - 2.5f;
+    float pl = 2.81022636e-08f; pl = fmaf(pl, wc, 3.43273939e-07f); pl = fmaf(pl, wc, -3.5233877e-06f); pl = fmaf(pl, wc, -4.39150654e-06f);
+    pl = fmaf(pl, wc, 0.00021858087f); pl = fmaf(pl, wc, -0.00125372503f); pl = fmaf(pl, wc, -0.00417768164f); pl = fmaf(pl, wc, 0.246640727f);
+    pl = fmaf(pl, wc, 1.50140941f);
+    if (__any(!tail && L >= 5.0f)) {
+        const float wf = r_sqrt(L) - 3.0f;
+        float pf = -0.000200214257f; pf = fmaf(pf, wf, 0.000100950558f); pf = fmaf(pf, wf, 0.00134934322f); pf = fmaf(pf, wf, -0.00367342844f);
+        pf = fmaf(pf, wf, 0.00573950773f); pf = fmaf(pf, wf, -0.0076224613f); pf = fmaf(pf, wf, 0.00943887047f); pf = fmaf(pf, wf, 1.00167406f);
+        pf = fmaf(pf, wf, 2.83297682f);
+        pl = (L >= 5.0f) ? pf : pl;
+    }
+    unsure = unsure || (!tail && L > 15.0f);
+    const float nz = 1.41421356237f * pl * (2.0f * pin - 1.0f);
+    const float nz2 = nz * nz;
+    // (b) small-z left piece kept iff u2 <= e^{-z^2 x / 2}
+    float x = r_rcp(nz2);
+    const float thr = r_exp(-0.5f * zf * zf * x);
+    bool ok = !(u2 > thr);
+    unsure = unsure || (!tail && !large && fabsf(u2 - thr) <= 1e-5f);
+    float e1 = -2.0f * nz2;
+    bool second = false;
+    if (__any(large && !tail)) {
+        // (c) IG(1/z, 1): second root iff u2 >= mu / (mu + x1); kept iff x <= t
+        const float mu = r_rcp(zf), ww = mu * nz2;
+        const float sq = r_sqrt(ww) * r_sqrt(4.0f + ww), den = sq + ww;
+        const float qq = den > 0.0f ? r_div(2.0f * r_sqrt(ww), den) : 1.0f;
+        const float x1 = mu * qq * qq;
+        const float thr2 = r_div(mu, mu + x1);
+        const bool sec = u2 >= thr2;
+        const float xl = sec ? r_div(mu * mu, x1) : x1;
+        if (large) {
+            x = xl; ok = !(xl > t); e1 = -2.0f * r_rcp(xl); second = sec;
+            unsure = unsure || (!tail && (fabsf(u2 - thr2) <= 1e-5f || fabsf(xl - t) <= 2e-5f || !(den > 0.0f)));
+        }
+    }
+    if (tail) { x = fmaf(L, rK, t); ok = true; e1 = -0.5f * PI * PI * x; }
+    // (d) V <= S_1 = 1 - 3 e^{2 e1}
+    const float S = 1.0f - 3.0f * r_exp(2.0f * e1);
+    bool accept = ok && V <= S;
+    unsure = unsure || (ok && fabsf(V - S) <= 1e-6f);
+    out = 0.25 * (double)x;
+    // ---- the accepted draw's value in fp64: ONE logarithm and ONE division per attempt serve every piece
+    //   tail            : x = t - log(u1) / K
+    //   left, z < 1/t   : x = 1 / Z^2,  Z = Phi^-1(u1 Phi(-1/sqrt t)) = sgn * num / den  (AS 241 rational)  =>  x = (den / num)^2
+    //   left, z >= 1/t  : Z = Phi^-1(u1) = sgn * num / den, then the inverse-Gaussian root from Z^2
+    if (__any(accept && !unsure)) {
+        const double PId = 3.14159265358979323846;
+        const double pa = large ? u1d : u1d * 0.10564977366685525;    // argument of the left piece's normal quantile
+        const double qc = pa - 0.5;
+        const bool central = fabs(qc) <= 0.425;
+        const double lg = fm::log(tail ? u1d : (qc < 0.0 ? pa : 1.0 - pa));
+        double num = lg, den = fma(0.5 * z, z, 0.125 * PId * PId);      // tail: log(u1) / K
+        if (__any(!tail && central)) {
+            double n, d;
+            as241::central(fma(-qc, qc, 0.180625), n, d);
+            n *= qc;                                                    // Z = qc n / d
+            if (!tail && central) { num = large ? n : d; den = large ? d : n; }
+        }
+        if (__any(!tail && !central)) {
+            const double r = fm::sqrt(-lg);
+            double n, d;
+            as241::mid(r, n, d);
+            if (__any(!tail && !central && r > 5.0)) { double n2, d2; as241::far(r, n2, d2); n = r > 5.0 ? n2 : n; d = r > 5.0 ? d2 : d; }
+            if (!tail && !central) { num = large ? n : d; den = large ? d : n; }   // |Z| = n / d (only Z^2 is used)
+        }
+        const double ratio = fm::div(num, den);
+        double x64 = tail ? 0.64 - ratio : ratio * ratio;
+        if (__any(large && !tail)) {
+            // IG(mu = 1/z, 1) from Z^2 (Michael-Schucany-Haas): with w = mu Z^2, x1 = 4 mu / (sqrt(4 + w) + sqrt(w))^2 and mu^2 / x1
+            const double mu = fm::rcp(large ? z : 2.0), w = (large && !tail) ? mu * ratio * ratio : 1.0;
+            const double sw = fm::sqrt(w), s4 = fm::sqrt(4.0 + w), sm = s4 + sw;
+            const double xl = second ? 0.25 * mu * sm * sm : fm::div(4.0 * mu, sm * sm);
+            x64 = (large && !tail) ? xl : x64;
+        }
+        if (accept) out = 0.25 * x64;
+    }
+    if (__any(unsure)) {
+        double o2;
+        const bool a2 = pg1_attempt_ref<double>(z, w0, w1, w2, w3, o2);
+        if (unsure) { accept = a2; out = o2; }
+    }
+    return accept;
 }
 
 // draw addressed by a stream: attempt k consumes block k

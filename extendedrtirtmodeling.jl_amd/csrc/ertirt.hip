@@ -242,9 +242,9 @@ template <typename real> struct Engine : EngineBase {
         }
         logW = 0; while ((1 << logW) < W) ++logW;
         IPL = (J + W - 1) / W;
-        const int max_threads = sizeof(real) == 8 ? 512 : ERM_F32_THREADS;
+        const int max_threads = sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_THREADS;
         block_threads = cfg.block_threads > 0 ? cfg.block_threads : max_threads;
-        if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= 1024 (fp32) / 512 (fp64)");
+        if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= " + std::to_string(ERM_F32_THREADS) + " (fp32) / " + std::to_string(ERM_F64_THREADS) + " (fp64)");
         const int R = 64 / W;
         // the per-wave item accumulators (nWaves x NSTAT x nItem doubles) dominate LDS for long tests: fewer waves per workgroup then
         if (cfg.block_threads == 0) {
@@ -252,12 +252,12 @@ template <typename real> struct Engine : EngineBase {
                 const size_t acc = (size_t)(block_threads / 64) * nstat(0) * J * sizeof(double);
                 const size_t fixed = (size_t)NITEMARR * J * sizeof(real) + (size_t)(stat_sizes(0) + 5 * J + 2 * J + TINY_WORK + 2 * PMAX * PMAX + 64) * sizeof(double);
                 if (acc + fixed <= 120 * 1024) break;
-                block_threads /= 2;
+                block_threads = std::max(64, block_threads / 2 / 64 * 64);
             }
         }
         const int nWaves = block_threads / 64;
         const int64_t need = (N + nWaves - 1) / nWaves;         // at least one subject per wave
-        const int per_cu = std::max(1, 16 / nWaves);
+        const int per_cu = sizeof(real) == 8 ? 1 : std::max(1, 16 / nWaves);       // resident workgroups per CU (the fp64 kernel's registers admit one)
         grid_blocks = cfg.grid_blocks > 0 ? cfg.grid_blocks : (int)std::min<int64_t>(need, (int64_t)cu_count * per_cu);
         if (grid_blocks < 1) grid_blocks = 1;
         // each workgroup owns a contiguous range of subjects, split evenly over its waves

@@ -113,7 +113,8 @@ static inline double orc_invgauss(orc_stream* s, double mu, double lambda)
 }
 
 /* ---- standard normal quantile: Giles' (2010) single-precision erfinv polynomial as a starting point,
- * polished by three Newton steps on Phi(x) = p evaluated through erfc in the lower tail (accurate to ~1e-15). */
+ * polished by Newton steps on Phi(x) = p evaluated through erfc in the lower tail (accurate to ~1e-15).  The device evaluates the
+ * same function directly by Wichura's AS 241 (csrc/erm_rng.hpp); tests/test_gpu_samplers.py compares both with each other and with Cephes. */
 static inline double orc_ndtri(double p)
 {
     int upper = p > 0.5;
@@ -132,10 +133,14 @@ static inline double orc_ndtri(double p)
         pl = 2.83297682 + pl * w;
     }
     double x = M_SQRT2 * pl * xx;                   /* <= 0 */
-    for (int it = 0; it < 3; ++it) {
+    /* three steps reach rounding level wherever the polynomial is a single-precision approximation (q > ~1e-7); beyond that it is
+     * extrapolated, so keep stepping until the step no longer changes x (at most 8 steps) */
+    for (int it = 0; it < 8; ++it) {
         double cdf = 0.5 * erfc(-x * M_SQRT1_2);
         double pdf = 0.3989422804014327 * exp(-0.5 * x * x);
-        x -= (cdf - q) / pdf;
+        double dx = (cdf - q) / pdf;
+        x -= dx;
+        if (it >= 2 && fabs(dx) <= 4e-16 * fabs(x)) break;
     }
     return upper ? -x : x;
 }

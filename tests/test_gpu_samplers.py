@@ -41,6 +41,48 @@ def test_pg1_f64_matches_oracle():
     assert np.max(np.abs(d - o) / o) < 1e-10
 
 
+def test_pg1_f64_filtered_decisions_are_the_reference_decisions():
+    """The fp64 engine's attempt takes its accept / reject decisions in fp32 behind guard bands and evaluates only the accepted value in
+    fp64 (erm_rng.hpp, pg1_attempt(double)).  Against the reference form of the attempt (every statement in fp64) on 2^24 draws:
+    a flipped decision would show as a different draw altogether; rounding of the value alone stays below 1e-13."""
+    n = 1 << 22
+    g = np.random.default_rng(5)
+    for k, c in enumerate((g.normal(0, 2.5, n), g.uniform(-3.2, 3.2, n), g.uniform(3.0, 7.0, n), np.concatenate([g.uniform(19.0, 26.0, n // 2), g.uniform(0, 1e-3, n // 2)]))):
+        fast, ref = _dev(3, n, c, sweep=11 + k), _dev(10, n, c, sweep=11 + k)
+        assert np.max(np.abs(fast - ref) / ref) < 1e-13
+    o = pu.orc_sample(3, N, c[:N], sweep=14)
+    assert np.max(np.abs(fast[:N] - o) / o) < 1e-10
+
+
+def test_ndtri_f64_is_as241_and_matches_the_oracles_newton_form():
+    from scipy.special import ndtri
+    g = np.random.default_rng(6)
+    p = np.concatenate([g.uniform(0, 1, N), 10.0 ** g.uniform(-11, -1, N), 1.0 - 10.0 ** g.uniform(-11, -1, N), np.linspace(0.07, 0.08, 1001), [0.075, 0.925, 0.5]])
+    d = _dev(9, p.size, p)
+    ref = ndtri(p)
+    assert np.max(np.abs(d - ref) / np.maximum(np.abs(ref), 0.1)) < 1e-14        # scipy (Cephes): independent of both implementations
+    o = pu.orc_sample(9, p.size, p)
+    assert np.max(np.abs(d - o) / np.maximum(np.abs(o), 0.1)) < 1e-13
+
+
+def test_fp64_cell_path_elementary_functions():
+    """fm::log / exp_neg / sqrt / div (erm_rng.hpp): range-specialised fp64 forms of the cell path, against numpy (libm)."""
+    g = np.random.default_rng(8)
+    x = np.concatenate([g.uniform(0, 1, N), 10.0 ** g.uniform(-12, 2, N), 1.0 + g.uniform(-1e-6, 1e-6, 1000), [1.0, 0.5, 2.0, 2.0 ** -0.5]])
+    d = _dev(11, x.size, x)
+    assert np.max(np.abs(d - np.log(x)) / np.maximum(np.abs(np.log(x)), 1e-8)) < 4e-16 * 8
+    assert _dev(11, 1, np.array([1.0]))[0] == 0.0
+    a = np.concatenate([g.uniform(0, 40, N), g.uniform(0, 1e-3, 1000), g.uniform(600, 800, 1000), [0.0]])
+    d = _dev(12, a.size, a)
+    ref = np.exp(-np.minimum(a, 700.0))
+    assert np.max(np.abs(d - ref) / ref) < 2e-15
+    d = _dev(13, x.size, x)
+    assert np.max(np.abs(d - np.sqrt(x)) / np.sqrt(x)) < 3e-16
+    y = 10.0 ** g.uniform(-6, 6, x.size) * g.choice([-1.0, 1.0], x.size)
+    d = _dev(14, x.size, y, x)
+    assert np.max(np.abs(d - y / x) / np.abs(y / x)) < 3e-16
+
+
 def test_pg1_f32_matches_oracle_except_rare_flips():
     g = np.random.default_rng(1)
     c = g.normal(0, 2.5, N)
