@@ -81,6 +81,7 @@ template <typename real> struct PassArgs {
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // diagnostics only: skip everything after stage k (0 = run everything)
     unsigned long long* dbg_ts;   // diagnostics only (ERM_TIMELINE): [2 workgroups][16 waves][16 checkpoints] of the 100 MHz wall clock
+    int pgq_off;          // fp64 engine: byte offset in dynamic LDS of the PG phase's value queues ([nWaves][4][128] x 8 bytes)
     uint32_t row_base;    // subject index of local row 0 in the whole data set (subject-sharded chains; 0 otherwise): the random streams are
                           // addressed by the GLOBAL subject index, so a chain does not depend on how its subjects are spread over devices
 };
@@ -995,6 +996,70 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
         // (letting a wave whose queue ran dry serve other waves' queues was tried: the hardware favours a SIMD's oldest wave, so the
         // four waves of a SIMD finish up to 17 us apart -- but the phase is VALU-throughput-bound, the SIMD is busy until the last
         // one ends either way, and the stealing logic only added instructions: 78.5 vs 75.3 us per sweep)
+        if constexpr (sizeof(real) == 8) {
+            // fp64 engine.  An attempt is DECIDED in fp32 behind guard bands (pg1_filter); the fp64 value of an accepted draw costs 30-70
+            // fp64 instructions that differ by piece of the envelope (tail: log + division; left: one of AS 241's rationals; z >= 1/t: the
+            // inverse-Gaussian root).  Evaluated inside the attempt loop every wave would run every piece on every trip with a fraction of
+            // its lanes.  Instead an accepted lane files (cell, word 1) in a wave-private LDS queue of its piece and moves on; whenever a
+            // queue holds 64 entries the whole wave evaluates that ONE piece for 64 cells, every lane busy, and stores the omegas.
+            // Positions come from ballots (wave-synchronous: no atomics); the value depends only on (cell, word 1), never on the lane.
+            constexpr int QCAP = 128;                                // a queue holds < 64 entries before a push of <= 64
+            uint2* pq = reinterpret_cast<uint2*>(smem + A.pgq_off) + (size_t)wave * 4 * QCAP;
+            int qhd[4] = {0, 0, 0, 0}, qn[4] = {0, 0, 0, 0};         // wave-uniform: first entry and number of entries per piece
+            auto flush = [&](int T, int n) {                         // evaluate and store the first n (<= 64) entries of queue T
+                wave_sync();
+                const bool on = lane < n;
+                const uint2 e = pq[T * QCAP + ((qhd[T] + (on ? lane : 0)) & (QCAP - 1))];
+                const int cc = (int)(e.x & 0x7FFFFFFFu);
+                int r2, j2;
+                locate(cc, r2, j2);
+                const double zz = 0.5 * fabs((double)sh_a[j2] * ((double)sh_th[r2] - (double)sh_b[j2]));
+                double x;
+                if (T == 0) x = pg1_value_tail(zz, e.y);
+                else if (T == 1) x = pg1_value_central(e.y);
+                else if (T == 2) x = pg1_value_mid(e.y);
+                else x = pg1_value_large(zz >= 1.5625 ? zz : 2.0, e.y, (e.x >> 31) != 0u);
+                if (on) om[cc] = (real)(0.25 * x);
+                qhd[T] += n; qn[T] -= n;
+            };
+            while (__any(active)) {
+                ++n_trip; n_att += active ? 1u : 0u;
+                int piece = PG_NONE;
+                uint2 ent = make_uint2(0u, 0u);
+                if (active) {
+                    uint32_t w0, w1, w2, w3;
+                    philox4x32_10((uint32_t)(ra + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                    const PgDecision d = pg1_filter((double)z, w0, w1, w2, w3);
+                    bool acc_ = d.accept;
+                    if (__any(d.unsure)) {                           // inside a guard band: the reference form decides, and its value is stored at once
+                        double o2;
+                        const bool a2 = pg1_attempt_ref<double>((double)z, w0, w1, w2, w3, o2);
+                        if (d.unsure) { acc_ = a2; if (a2) om[c] = (real)o2; }
+                    }
+                    const bool give_up = att + 1u >= (uint32_t)MAX_TRIES;
+                    if (acc_ || give_up) {
+                        if (acc_ && !d.unsure) { piece = d.piece; ent = make_uint2((uint32_t)c | (d.second ? 0x80000000u : 0u), w1); }
+                        else if (!acc_) om[c] = (real)(0.25 * (double)d.x);
+                        c = (int)atomicAdd(qhead, 1u);
+                        att = 0;
+                        active = c < ncell;
+                        if (active) { locate(c, rr, j); th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
+                    } else ++att;
+                }
+#pragma unroll
+                for (int T = 0; T < 4; ++T) {
+                    const unsigned long long m = __ballot(piece == T + 1);
+                    if (m != 0ull) {
+                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (piece == T + 1) pq[T * QCAP + ((qhd[T] + qn[T] + pos) & (QCAP - 1))] = ent;
+                        qn[T] += __popcll(m);
+                        if (qn[T] >= 64) flush(T, 64);
+                    }
+                }
+            }
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { if (qn[T] > 0) flush(T, qn[T]); }
+        } else {
         while (__any(active)) {
             ++n_trip; n_att += active ? 1u : 0u;
             if (active) {
@@ -1010,6 +1075,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                     if (active) { locate(c, rr, j); th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
                 } else ++att;
             }
+        }
         }
         if (A.dbg_stop == 9) {
             Ctl* cw = const_cast<Ctl*>(A.ctl);

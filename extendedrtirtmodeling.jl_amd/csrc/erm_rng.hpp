@@ -393,13 +393,23 @@ __device__ __forceinline__ bool pg1_attempt(float z, uint32_t w0, uint32_t w1, u
 // with the hardware-rate fp32 instructions first.  Each comes with a guard band several times wider than the worst fp32 error of its two
 // sides (derivations in DESIGN.md 4b): outside the band the fp32 outcome IS the fp64 outcome; a lane inside a band (about 4 in 10^5
 // attempts), with z > 10, or with a quantile argument below 2^-22 (where Giles' polynomial is extrapolated) repeats the attempt through
-// pg1_attempt_ref<double>.  Only an ACCEPTED draw is then evaluated in fp64, and only its value: one log, one AS 241 quantile or
-// one division -- instead of three fp64 exponentials, a log and a quantile per attempt.  Decisions, and therefore which Philox block a
-// cell's draw comes from, are those of the reference form; the value differs from it by rounding only (tests: draw by draw against the
-// oracle, and against pg1_attempt_ref on 2^24 draws).
+// pg1_attempt_ref<double>.  Only an ACCEPTED draw is then evaluated in fp64, and only its value (pg1_value_*): one log and one division
+// (tail), one AS 241 rational (left) -- instead of three fp64 exponentials, a log and a quantile per attempt.  Decisions, and therefore
+// which Philox block a cell's draw comes from, are those of the reference form; the value differs from it by rounding only (tests: draw
+// by draw against the oracle, and against pg1_attempt_ref on 2^24 draws).
 //   the series needs no second term: rho_2 = 5 e^{6 e1} <= 3.6e-8 for every x an attempt can propose (e^{2 e1} <= 1.93e-3), less than
 //   the band on V <= S_1, so V > S_1 + band implies V > S_2 (reject) and V <= S_1 - band implies accept.
-__device__ __forceinline__ bool pg1_attempt(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double& out)
+enum PgPiece : int { PG_NONE = 0, PG_TAIL = 1, PG_CENTRAL = 2, PG_MID = 3, PG_LARGE = 4 };   // which fp64 evaluation an accepted draw needs
+
+struct PgDecision {
+    bool accept;      // fp32 outcome of the attempt (final unless `unsure`)
+    bool unsure;      // some comparison fell inside its guard band: repeat through pg1_attempt_ref<double>
+    bool second;      // z >= 1/t: the second inverse-Gaussian root was taken
+    int piece;        // PgPiece of the proposal
+    float x;          // fp32 value of the proposal (diagnostic / give-up value)
+};
+
+__device__ __forceinline__ PgDecision pg1_filter(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
     const float t = 0.64f, PI = 3.14159265358979f;
     const float zf = (float)z;
@@ -455,48 +465,66 @@ __device__ __forceinline__ bool pg1_attempt(double z, uint32_t w0, uint32_t w1, 
     if (tail) { x = fmaf(L, rK, t); ok = true; e1 = -0.5f * PI * PI * x; }
     // (d) V <= S_1 = 1 - 3 e^{2 e1}
     const float S = 1.0f - 3.0f * r_exp(2.0f * e1);
-    bool accept = ok && V <= S;
-    unsure = unsure || (ok && fabsf(V - S) <= 1e-6f);
-    out = 0.25 * (double)x;
-    // ---- the accepted draw's value in fp64: ONE logarithm and ONE division per attempt serve every piece
-    //   tail            : x = t - log(u1) / K
-    //   left, z < 1/t   : x = 1 / Z^2,  Z = Phi^-1(u1 Phi(-1/sqrt t)) = sgn * num / den  (AS 241 rational)  =>  x = (den / num)^2
-    //   left, z >= 1/t  : Z = Phi^-1(u1) = sgn * num / den, then the inverse-Gaussian root from Z^2
-    if (__any(accept && !unsure)) {
-        const double PId = 3.14159265358979323846;
-        const double pa = large ? u1d : u1d * 0.10564977366685525;    // argument of the left piece's normal quantile
-        const double qc = pa - 0.5;
-        const bool central = fabs(qc) <= 0.425;
-        const double lg = fm::log(tail ? u1d : (qc < 0.0 ? pa : 1.0 - pa));
-        double num = lg, den = fma(0.5 * z, z, 0.125 * PId * PId);      // tail: log(u1) / K
-        if (__any(!tail && central)) {
-            double n, d;
-            as241::central(fma(-qc, qc, 0.180625), n, d);
-            n *= qc;                                                    // Z = qc n / d
-            if (!tail && central) { num = large ? n : d; den = large ? d : n; }
-        }
-        if (__any(!tail && !central)) {
-            const double r = fm::sqrt(-lg);
-            double n, d;
-            as241::mid(r, n, d);
-            if (__any(!tail && !central && r > 5.0)) { double n2, d2; as241::far(r, n2, d2); n = r > 5.0 ? n2 : n; d = r > 5.0 ? d2 : d; }
-            if (!tail && !central) { num = large ? n : d; den = large ? d : n; }   // |Z| = n / d (only Z^2 is used)
-        }
-        const double ratio = fm::div(num, den);
-        double x64 = tail ? 0.64 - ratio : ratio * ratio;
-        if (__any(large && !tail)) {
-            // IG(mu = 1/z, 1) from Z^2 (Michael-Schucany-Haas): with w = mu Z^2, x1 = 4 mu / (sqrt(4 + w) + sqrt(w))^2 and mu^2 / x1
-            const double mu = fm::rcp(large ? z : 2.0), w = (large && !tail) ? mu * ratio * ratio : 1.0;
-            const double sw = fm::sqrt(w), s4 = fm::sqrt(4.0 + w), sm = s4 + sw;
-            const double xl = second ? 0.25 * mu * sm * sm : fm::div(4.0 * mu, sm * sm);
-            x64 = (large && !tail) ? xl : x64;
-        }
-        if (accept) out = 0.25 * x64;
-    }
-    if (__any(unsure)) {
+    PgDecision d;
+    d.accept = ok && V <= S;
+    d.unsure = unsure || (ok && fabsf(V - S) <= 1e-6f);
+    d.second = second;
+    d.x = x;
+    // the quantile range of the left piece, from the fp64 argument exactly as AS 241 splits it
+    const double pa = large ? u1d : u1d * 0.10564977366685525;
+    d.piece = tail ? PG_TAIL : (large ? PG_LARGE : (fabs(pa - 0.5) <= 0.425 ? PG_CENTRAL : PG_MID));
+    return d;
+}
+
+// ---- fp64 value of an accepted proposal, one function per piece (each returns X; omega = X / 4)
+__device__ __forceinline__ double pg1_value_tail(double z, uint32_t w1)          // X = t - log(u1) / K
+{
+    const double PId = 3.14159265358979323846;
+    return 0.64 - fm::div(fm::log(word_to_unif<double>(w1)), fma(0.5 * z, z, 0.125 * PId * PId));
+}
+__device__ __forceinline__ double pg1_value_central(uint32_t w1)                 // X = 1 / Z^2, Z = Phi^-1(pa) = qc n / d
+{
+    const double qc = word_to_unif<double>(w1) * 0.10564977366685525 - 0.5;
+    double n, d;
+    as241::central(fma(-qc, qc, 0.180625), n, d);
+    const double ratio = fm::div(d, qc * n);
+    return ratio * ratio;
+}
+__device__ __forceinline__ double pg1_value_mid(uint32_t w1)                     // X = 1 / Z^2, |Z| = n / d
+{
+    const double r = fm::sqrt(-fm::log(word_to_unif<double>(w1) * 0.10564977366685525));
+    double n, d;
+    as241::mid(r, n, d);
+    if (__any(r > 5.0)) { double n2, d2; as241::far(r, n2, d2); n = r > 5.0 ? n2 : n; d = r > 5.0 ? d2 : d; }
+    const double ratio = fm::div(d, n);
+    return ratio * ratio;
+}
+// z >= 1/t: IG(mu = 1/z, 1) from Z = Phi^-1(u1) (Michael-Schucany-Haas): with w = mu Z^2, x1 = 4 mu / (sqrt(4 + w) + sqrt(w))^2, the
+// second root is mu^2 / x1 (the same roots as the reference form's 2 sqrt(w) / (sqrt(w) sqrt(4 + w) + w), divided through by sqrt(w))
+__device__ __forceinline__ double pg1_value_large(double z, uint32_t w1, bool second)
+{
+    const double Z = ndtri(word_to_unif<double>(w1));
+    const double mu = fm::rcp(z), w = mu * Z * Z;
+    const double sm = fm::sqrt(4.0 + w) + sqrt(w);
+    return second ? 0.25 * mu * sm * sm : fm::div(4.0 * mu, sm * sm);
+}
+
+// one whole attempt in the calling lane's own control flow (debug sampler, item-free callers); the row pass batches the value
+// evaluations by piece instead (erm_kernels.hpp, PG phase)
+__device__ __forceinline__ bool pg1_attempt(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double& out)
+{
+    const PgDecision d = pg1_filter(z, w0, w1, w2, w3);
+    bool accept = d.accept;
+    out = 0.25 * (double)d.x;
+    const bool go = accept && !d.unsure;
+    if (__any(go && d.piece == PG_TAIL)) { const double x = pg1_value_tail(z, w1); if (go && d.piece == PG_TAIL) out = 0.25 * x; }
+    if (__any(go && d.piece == PG_CENTRAL)) { const double x = pg1_value_central(w1); if (go && d.piece == PG_CENTRAL) out = 0.25 * x; }
+    if (__any(go && d.piece == PG_MID)) { const double x = pg1_value_mid(w1); if (go && d.piece == PG_MID) out = 0.25 * x; }
+    if (__any(go && d.piece == PG_LARGE)) { const double x = pg1_value_large(d.piece == PG_LARGE ? z : 2.0, w1, d.second); if (go && d.piece == PG_LARGE) out = 0.25 * x; }
+    if (__any(d.unsure)) {
         double o2;
         const bool a2 = pg1_attempt_ref<double>(z, w0, w1, w2, w3, o2);
-        if (unsure) { accept = a2; out = o2; }
+        if (d.unsure) { accept = a2; out = o2; }
     }
     return accept;
 }

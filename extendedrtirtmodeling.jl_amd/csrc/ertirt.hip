@@ -206,8 +206,10 @@ template <typename real> struct Engine : EngineBase {
     size_t pass_lds(int phase, int nWaves) const {
         const int ng = stat_sizes(phase) - nstat(phase) * J;
         size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * ((size_t)nstat(phase) * J + (size_t)ng);
-        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave + (size_t)rows_per_block * (Fk + 4)) * sizeof(real);
+        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave + (size_t)rows_per_block * (Fk + 4)) * sizeof(real) + pgq_bytes(nWaves);
     }
+    // fp64 engine: the PG phase's per-wave value queues (4 pieces x 128 entries x 8 bytes), at the very end of the dynamic LDS of a launch
+    static size_t pgq_bytes(int nWaves) { return sizeof(real) == 8 ? (size_t)nWaves * 4 * 128 * 8 + 8 : 0; }
 
     int init() override {
         N = cfg.n_subj; J = cfg.n_item; F = cfg.n_feat;
@@ -389,6 +391,10 @@ template <typename real> struct Engine : EngineBase {
         { const char* e = getenv("ERM_PASS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
         a.dbg_ts = dDbgTs.as<unsigned long long>();
         a.row_base = (uint32_t)row_base;
+        {   // the queues close the launch's dynamic LDS (8-byte aligned)
+            const size_t total = fz ? fused_lds() : lds_pass[phase];
+            a.pgq_off = (int)((total - pgq_bytes(block_threads / 64) + 7) & ~(size_t)7);
+        }
         return a;
     }
     TinyArgs tiny_args(int mode, int first, bool fz = false) const {
