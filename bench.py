@@ -4,11 +4,19 @@
 A "step" is ONE Gibbs sweep (every full conditional of one `for m, l` iteration of sample!) over one synthetic data set
 that is already resident in HBM.  Default workload: GibbsRtIrt, nSubj=100000, nItem=50, nFeat=3 (BASELINE.json configs[2],
 the configuration the north-star target is quoted on); data per setDataRtIrt's distributions, fixed seed.
+
+Headline = the fp64 engine (`dtype: f64`): the reference's arithmetic is Float64 throughout (src/Base.pl.jl:67-78, the Post arrays).
+The fp32 fast mode (fp32 cell arithmetic, fp64 accumulation) is measured in the same invocation on the same resident inputs and
+carried in the same JSON line as the nested object `fp32`.
+
 N GPUs = N independent chains (one process per GPU, chain_id = rank, no data-path collective): "scaling": "weak".
+`python bench.py --gpus N` creates its N ranks itself when it is not already running under torch.distributed.run: the parent --
+which never touches HIP or torch -- starts N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and relays rank 0's line.
 After the timed region the ranks all-reduce their posterior summaries over RCCL (timed separately, reported as gather_ms).
+At N > 1 the line also carries `configs4`: the same measurement on BASELINE.json configs[4]'s per-GPU load (500000 x 100).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (the fused row pass): algorithmic bytes per launch / mean launch duration measured live with
+  roofline     -- dominant kernel (the fused sweep kernel): algorithmic bytes per launch / mean launch duration measured live with
                   HIP events on the engine's stream, against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle (kind "port": fp64 C restatement of the reference's un-fused schedule, 1 thread) timed on this
                   host for a bounded number of sweeps of the SAME workload.  The reference itself is Julia and cannot run here.
@@ -21,20 +29,77 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # the oracle's OpenMP threads must not spin on a shared host
-import __graft_entry__ as ge  # noqa: E402
 
-ALGO_BYTES = {"mlirt": 9, "rtirt": 13, "latentqr": 13, "crossqr": 29,          # fp32 matrices, Y as 1 byte
-              "null": 13, "latent": 13, "cross": 17}                        # variants: as their families; Cross: omega r/w, Y, logT twice, no nu
+# algorithmic bytes per cell-update, Y as 1 byte; matrices in the engine's cell type (fp32: 4 B, fp64: 8 B)
+#   MlIrt: Y + omega read + omega write; RtIrt / LatentQr (+ variants): + logT; CrossQr: two passes (omega r, Y, logT, nu r | logT, nu r, nu w, omega w);
+#   Cross: omega r/w, Y, logT twice, no nu
+ALGO_BYTES = {"f32": {"mlirt": 9, "rtirt": 13, "latentqr": 13, "crossqr": 29, "null": 13, "latent": 13, "cross": 17},
+              "f64": {"mlirt": 17, "rtirt": 25, "latentqr": 25, "crossqr": 57, "null": 25, "latent": 25, "cross": 33}}
 FAMILY = {"null": "rtirt", "latent": "latentqr", "cross": "crossqr"}
 HBM_PEAK_GBS = 8000.0                                                     # MI355X_MICROARCH.md: 8.0 TB/s spec
+NAMES = {'mlirt': 'MlIrt', 'rtirt': 'RtIrt', 'latentqr': 'RtIrtLatentQr', 'crossqr': 'RtIrtCrossQr', 'null': 'RtIrtNull', 'cross': 'RtIrtCross', 'latent': 'RtIrtLatent'}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--model", default="rtirt", choices=list(ALGO_BYTES["f32"]))
+    ap.add_argument("--nsubj", type=int, default=100000)
+    ap.add_argument("--nitem", type=int, default=50)
+    ap.add_argument("--nfeat", type=int, default=3)
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64"], help="engine of the headline value (default: the reference's Float64)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the nested fp32 fast-mode measurement")
+    ap.add_argument("--no-configs4", action="store_true", help="at N > 1: skip the nested measurement on configs[4]'s per-GPU load (500000 x 100)")
+    ap.add_argument("--trace", default="full", choices=["full", "summary"])
+    ap.add_argument("--lanes-per-row", type=int, default=0)
+    ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--grid-blocks", type=int, default=0)
+    ap.add_argument("--cpu-sweeps", type=int, default=-1, help="oracle sweeps for cpu_baseline (-1 = auto ~15 s, 0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket sweep-kernel launches with HIP events")
+    ap.add_argument("--shard-exchange", default="rccl", choices=["rccl", "callback"], help="--shard: in-stream RCCL all-gather (default) or the "
+                                                        "host callback over torch.distributed")
+    ap.add_argument("--shard", action="store_true", help="NOT the headline: ONE chain of --nsubj subjects sharded over the ranks (strong scaling; "
+                                                        "one all-gather of a statistics row per row pass, SURVEY.md 8(e))")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torch.distributed.run.  Runs in a process that has imported neither torch nor the HIP
+# library (a process that has initialised the GPU must never exec or be replaced; this one only waits for its children).
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ERM_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    line = None
+    for ln in (out or "").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(rcs) or line is None:
+        print(f"bench.py: ranks exited with {rcs}" + ("" if line else "; rank 0 printed no result line"), file=sys.stderr)
+        return max([abs(rc) for rc in rcs] + [1])
+    print(line, flush=True)
+    return 0
 
 
 def make_data(pkg, model, N, J, F, seed):
+    import numpy as np
     Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=F, nIter=10, nChain=1, qRt=0.85)
     g = np.random.default_rng(seed)
     if model == "mlirt":
@@ -52,6 +117,7 @@ def make_data(pkg, model, N, J, F, seed):
 
 
 def init_state(model, N, J, F, rank):
+    import numpy as np
     g = np.random.default_rng([99, rank])
     st = dict(theta=g.standard_normal(N))
     if model != "mlirt":
@@ -105,78 +171,21 @@ def cpu_baseline(model, Y, logT, X, st, sweeps, threads=1, budget_s=30.0):
         pu.oracle().orc_set_threads(1)
 
 
-def traffic_bytes(model, N, J, args):
-    """HBM-side bytes per pass_kernel launch from the PMC counters.  Counters cannot be read from inside this process; they are
-    collected by tools/collect_profiles.sh in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this same command and
-    stored, with the gfx950 FETCH_SIZE x2 correction calibrated on a known byte count, in profiles/traffic.json.  Returned only
-    when that file describes exactly this workload; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None
+def offline_counters(model, N, J, precision):
+    """PMC counters cannot be read from inside this process: they are collected by tools/collect_profiles.sh in separate rocprofv3
+    --pmc passes of this same command and kept, with the gfx950 FETCH_SIZE correction calibrated on a known byte count, in
+    profiles/traffic.json.  Returned (labelled as offline) only when that file describes exactly this workload and precision."""
     try:
-        t = json.load(open(path))
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{model}:{N}x{J}:{precision}")
     except Exception:
         return None
-    key = f"{model}:{N}x{J}:{args.precision}"
-    e = t.get(key)
-    return None if e is None else e.get("traffic_bytes_per_launch")
+    return e
 
 
-def valu_profile(model, N, J, args):
-    """VALU-side counters of the same offline profile (profiles/traffic.json), or None: the kernel's real limiter."""
-    try:
-        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{model}:{N}x{J}:{args.precision}")
-        return None if e is None else e.get("valu")
-    except Exception:
-        return None
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--model", default="rtirt", choices=list(ALGO_BYTES))
-    ap.add_argument("--nsubj", type=int, default=100000)
-    ap.add_argument("--nitem", type=int, default=50)
-    ap.add_argument("--nfeat", type=int, default=3)
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--trace", default="full", choices=["full", "summary"])
-    ap.add_argument("--lanes-per-row", type=int, default=0)
-    ap.add_argument("--block-threads", type=int, default=0)
-    ap.add_argument("--grid-blocks", type=int, default=0)
-    ap.add_argument("--cpu-sweeps", type=int, default=-1, help="oracle sweeps for cpu_baseline (-1 = auto ~15 s, 0 = skip)")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket row-pass launches with HIP events")
-    ap.add_argument("--shard-exchange", default="rccl", choices=["rccl", "callback"], help="--shard: in-stream RCCL all-gather (default) or the "
-                                                        "host callback over torch.distributed")
-    ap.add_argument("--shard", action="store_true", help="NOT the headline: ONE chain of --nsubj subjects sharded over the ranks (strong scaling; "
-                                                        "one all-gather of a statistics row per row pass, SURVEY.md 8(e))")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rehearse = os.environ.get("ERM_BENCH_REHEARSE") == "1"
-    coll_dev = "cpu" if rehearse else None
-    import torch
-    dist = None
-    if world > 1 or os.environ.get("ERM_BENCH_FORCE_DIST") == "1":     # FORCE_DIST: exercise the RCCL calls with one rank on a one-GPU box
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:     # ERM_BENCH_REHEARSE=1: the N>1 code path on a ONE-GPU box -- every rank on cuda:0, collectives over gloo on the CPU
-            local_rank = 0
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    ge.build_hip()
-    pkg = ge.load_package()
+def measure(pkg, ge_mod, torch, dist, args, model, N, J, F, precision, data, st, rank, world, local_rank, rehearse, shard, trace):
+    """warm-up + timed region of one engine on resident inputs; returns (dt seconds [max over ranks], timing dict, engine, n_loc)."""
     L = pkg._lib
-    model, N, J, F = args.model, args.nsubj, args.nitem, args.nfeat
-    Y, logT, X = make_data(pkg, model, N, J, F, seed=1234)
-    shard = args.shard and dist is not None
-    st = init_state(model, N, J, F, 0 if shard else rank)
+    Y, logT, X = data
     rows = args.warmup + args.steps
     lo, n_loc = (0, N)
     if shard:       # every rank builds the same data set and keeps its rows
@@ -185,9 +194,10 @@ def main():
         st = dict(st, **{k: st[k][lo:lo + n_loc] for k in ("theta", "zeta") if k in st})
     eng = L.Engine(model=getattr(L, "MODEL_" + model.upper()), n_item=J, n_subj=n_loc, n_feat=0 if X is None else F, n_iter=rows, n_chain=1,
                    n_burnin=args.warmup, cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, chain_id=0 if shard else rank, device=local_rank,
-                   precision=L.PREC_F32 if args.precision == "f32" else L.PREC_F64,
-                   trace_mode=L.TRACE_FULL if args.trace == "full" else L.TRACE_SUMMARY, lanes_per_row=args.lanes_per_row,
+                   precision=L.PREC_F32 if precision == "f32" else L.PREC_F64,
+                   trace_mode=L.TRACE_FULL if trace == "full" else L.TRACE_SUMMARY, lanes_per_row=args.lanes_per_row,
                    block_threads=args.block_threads, grid_blocks=args.grid_blocks, profile=0 if args.no_profile else 1)
+    coll_dev = "cpu" if rehearse else f"cuda:{local_rank}"
     if shard and (rehearse or args.shard_exchange == "callback"):
         eng.set_shard(rank, world, N, lo, pkg.parallel.TorchExchange(L.load(), device=None if rehearse else f"cuda:{local_rank}"))
     elif shard:     # the library's own in-stream RCCL all-gather; the 128-byte id travels over the process group
@@ -211,9 +221,90 @@ def main():
     dt = time.perf_counter() - t0
     tm = eng.timing()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev or f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt, tm, eng, n_loc
+
+
+def roofline(model, N, J, n_loc, precision, tm):
+    if tm["pass_launches"] <= 0:
+        return None
+    per_launch_s = tm["pass_ms_total"] / tm["pass_launches"] * 1e-3
+    launches_per_sweep = 2 if model in ("crossqr", "cross") else 1
+    algo = ALGO_BYTES[precision][model] * float(n_loc) * J / launches_per_sweep        # a launch covers this rank's subjects
+    ach = algo / per_launch_s / 1e9
+    off = offline_counters(model, N, J, precision)
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "traffic": None if off is None else off.get("traffic_bytes_per_launch"),
+           "traffic_source": None if off is None else f"offline rocprofv3 --pmc passes of this command ({off.get('source', 'profiles/traffic.json')}); not measured in this run",
+           "kernel": f"pass_kernel<{model}, {'float' if precision == 'f32' else 'double'}> (one launch per sweep: tiny step + fused row pass; Cross family: one of its two row passes)",
+           "frac_of_achievable": ach / 6300.0, "achievable_peak": 6300.0, "launch_us": per_launch_s * 1e6, "event_overhead_us": tm["event_overhead_ms"] * 1e3,
+           "algorithmic_bytes_per_cell_update": ALGO_BYTES[precision][model], "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"]),
+           "launch_us_source": "HIP events on the engine's stream around sweep-kernel launches of the timed region (live)"}
+    if off is not None and off.get("valu") is not None:
+        out["valu"] = dict(off["valu"], source="offline rocprofv3 SQ counters (profiles/), not measured in this run")
+    return out
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # not under torch.distributed.run: make the ranks ourselves (nothing GPU-related has been imported in this process)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np  # noqa: F401
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # the oracle's OpenMP threads must not spin on a shared host
+    import __graft_entry__ as ge
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(world_env or "1")
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    rehearse = os.environ.get("ERM_BENCH_REHEARSE") == "1"
+    import torch
+    dist = None
+    backend = None
+    if world > 1 or os.environ.get("ERM_BENCH_FORCE_DIST") == "1":     # FORCE_DIST: exercise the RCCL calls with one rank on a one-GPU box
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if rehearse:     # ERM_BENCH_REHEARSE=1: the N>1 code path on a ONE-GPU box -- every rank on cuda:0, collectives over gloo on the CPU
+            local_rank = 0
+            backend = "gloo"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            backend = "nccl"
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world
+
+    if os.environ.get("ERM_BENCH_LAUNCH_ONLY") == "1":
+        # launcher self-test (tests/test_bench_launcher.py, runs without a GPU): the ranks exist, rendezvous and reduce; no engine is created
+        tot = None
+        if dist is not None:
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(t)
+            tot = float(t.item())
+        if rank == 0:
+            print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "ranks": world, "rank_sum": tot, "backend": backend, "steps": args.steps}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ge.build_hip()
+    pkg = ge.load_package()
+    model, N, J, F = args.model, args.nsubj, args.nitem, args.nfeat
+    data = make_data(pkg, model, N, J, F, seed=1234)
+    shard = args.shard and dist is not None
+    st = init_state(model, N, J, F, 0 if shard else rank)
+
+    common = dict(pkg=pkg, ge_mod=ge, torch=torch, dist=dist, args=args, rank=rank, world=world, local_rank=local_rank, rehearse=rehearse, shard=shard)
+    prec = args.precision
+    dt, tm, eng, n_loc = measure(model=model, N=N, J=J, F=F, precision=prec, data=data, st=st, trace=args.trace, **common)
 
     # posterior-summary gather over RCCL (outside the timed region; this is the only collective of the path)
     gather_ms = None
@@ -228,6 +319,30 @@ def main():
         pkg.parallel.gather_posterior_summaries(P, eng.post_count, device=None if rehearse else f"cuda:{local_rank}")
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+    del eng
+
+    # the fp32 fast mode on the same resident-input protocol (every rank takes part: the barriers are collective)
+    fp32 = None
+    if prec == "f64" and not args.no_fp32 and not shard:
+        dt32, tm32, eng32, _ = measure(model=model, N=N, J=J, F=F, precision="f32", data=data, st=st, trace=args.trace, **common)
+        del eng32
+        fp32 = {"value": float(N) * J * args.steps * world / dt32, "unit": "cell-updates/s", "ms_per_step": dt32 / args.steps * 1e3, "dtype": "f32",
+                "note": "fp32 cell arithmetic, fp64 accumulation and item-level draws; same workload, steps and warm-up",
+                "roofline": roofline(model, N, J, N, "f32", tm32)}
+
+    # configs[4]'s per-GPU load, one chain per GPU (BASELINE.json: GibbsRtIrt 500000 x 100, nChain = 8 over 8 GPUs)
+    cfg4 = None
+    if world > 1 and not shard and not args.no_configs4 and model == "rtirt" and (N, J) != (500000, 100):
+        N4, J4 = (20000, 100) if rehearse else (500000, 100)
+        a4 = argparse.Namespace(**vars(args))
+        a4.steps, a4.warmup = min(args.steps, 100), min(args.warmup, 10)
+        data4 = make_data(pkg, model, N4, J4, F, seed=1234)
+        st4 = init_state(model, N4, J4, F, rank)
+        dt4, tm4, eng4, _ = measure(model=model, N=N4, J=J4, F=F, precision=prec, data=data4, st=st4, trace="summary", **dict(common, args=a4))
+        del eng4
+        cfg4 = {"workload": f"GibbsRtIrt nSubj={N4} nItem={J4} nFeat={F}, one chain per GPU (BASELINE.json configs[4] per-GPU load), summary traces",
+                "value": float(N4) * J4 * a4.steps * world / dt4, "unit": "cell-updates/s", "ms_per_step": dt4 / a4.steps * 1e3, "steps": a4.steps, "warmup": a4.warmup,
+                "dtype": prec, "roofline": roofline(model, N4, J4, N4, prec, tm4)}
 
     if rank == 0:
         cells = float(N) * J
@@ -235,27 +350,25 @@ def main():
         out = {
             "metric": "Gibbs cell-updates/s (nSubj x nItem x sweeps/s)", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"Gibbs{ {'mlirt': 'MlIrt', 'rtirt': 'RtIrt', 'latentqr': 'RtIrtLatentQr', 'crossqr': 'RtIrtCrossQr', 'null': 'RtIrtNull', 'cross': 'RtIrtCross', 'latent': 'RtIrtLatent'}[model] } "
-                                   f"nSubj={N} nItem={J} nFeat={F} " + (f"ONE chain, subjects sharded over {world} devices" if shard else "nChain=1 per GPU (BASELINE.json configs[2])"),
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": f"Gibbs{NAMES[model]} nSubj={N} nItem={J} nFeat={F} " + (f"ONE chain, subjects sharded over {world} devices" if shard else "nChain=1 per GPU (BASELINE.json configs[2])"),
                        "chains": 1 if shard else world, "subject_shards": world if shard else 1, "shard_exchange": (("callback" if rehearse else args.shard_exchange) if shard else None), "trace": args.trace, "lanes_per_row": tm["lanes_per_row"], "block_threads": tm["block_threads"],
-                       "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"]},
+                       "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"], "ranks": world, "collective_backend": backend,
+                       "rccl_ranks": world if backend == "nccl" else 0},
             "sweeps_per_s": args.steps * (1 if shard else world) / dt, "device_ms_per_step": tm["run_ms"] / args.steps,
         }
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
-        if tm["pass_launches"] > 0:
-            per_launch_s = tm["pass_ms_total"] / tm["pass_launches"] * 1e-3
-            launches_per_sweep = 2 if model in ("crossqr", "cross") else 1
-            algo = ALGO_BYTES[model] * float(n_loc) * J / launches_per_sweep        # a launch covers this rank's subjects
-            ach = algo / per_launch_s / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic_bytes(model, N, J, args), "kernel": "pass_kernel (one launch per sweep: tiny step + fused row pass; CrossQr: one of its two row passes)",
-                               "frac_of_achievable": ach / 6300.0, "achievable_peak": 6300.0, "launch_us": per_launch_s * 1e6, "event_overhead_us": tm["event_overhead_ms"] * 1e3,
-                               "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"]),
-                               "valu": valu_profile(model, N, J, args)}
+        rf = roofline(model, N, J, n_loc, prec, tm)
+        if rf is not None:
+            out["roofline"] = rf
+        if fp32 is not None:
+            out["fp32"] = fp32
+        if cfg4 is not None:
+            out["configs4"] = cfg4
         ncpu = args.cpu_sweeps
         if ncpu != 0 and world == 1:          # the CPU baseline is reported at N=1 only
+            Y, logT, X = data
             if ncpu < 0:
                 ncpu = max(2, int(round(15.0 / (cells * 2.6e-7))))      # ~0.26 us per cell-update on one host core
             sec, nrun = cpu_baseline(model, Y, logT, X, st, ncpu, budget_s=25.0)

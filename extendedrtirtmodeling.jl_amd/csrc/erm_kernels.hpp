@@ -35,7 +35,7 @@ struct Ctl {
     uint32_t row;         // trace row of that sweep within the current sample! call
     uint32_t burn_rows;   // rows < burn_rows are burn-in (not accumulated into Post.mean)
     uint32_t err;         // sticky non-finite flag
-    unsigned long long dbg_attempts, dbg_trips, dbg_cells;   // diagnostics (ERM_PASS_STOP=9): PG attempts, wave trips, cells
+    unsigned long long dbg_attempts, dbg_trips, dbg_cells;   // -DERM_DIAG_BUILD with ERM_PASS_STOP=9: PG attempts, wave trips, cells
 };
 
 // parameter block written by the tiny step (fp64): a, b, lambda, sig2t, rho : 5 x J, then Sigp(4), beta(2*PMAX),
@@ -79,7 +79,7 @@ template <typename real> struct PassArgs {
     int ngx;              // extra global statistics inserted before the log-likelihood slot (LatentQr sigp_mode 1: the 1/nu-weighted Gram entries)
     int skew;             // FUSED kernels: subjects taken off wave 0's slice (it runs the structural chain of the tiny step first)
     uint32_t chain; uint64_t seed; double k1, k2;
-    int dbg_stop;         // diagnostics only: skip everything after stage k (0 = run everything)
+    int dbg_stop;         // -DERM_DIAG_BUILD only: skip everything after stage k (0 = run everything); ignored by the shipped library
     unsigned long long* dbg_ts;   // diagnostics only (ERM_TIMELINE): [2 workgroups][16 waves][16 checkpoints] of the 100 MHz wall clock
     int pgq_off;          // fp64 engine: byte offset in dynamic LDS of the PG phase's value queues ([nWaves][4][128] x 8 bytes)
     uint32_t row_base;    // subject index of local row 0 in the whole data set (subject-sharded chains; 0 otherwise): the random streams are
@@ -121,6 +121,16 @@ constexpr double LOG_2PI = 1.8378770664093454836;
 constexpr int GROUP = 16;  // workgroups whose slab rows are summed by the last of them to finish
 constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
 
+// Stage-timing / counting diagnostics (early returns that leave GARBAGE results, PG attempt counters) exist only in a library built with
+// -DERM_DIAG_BUILD (tools/tiny_stages.sh); the shipped library has no such code path, so no environment variable can corrupt a fit.
+#ifdef ERM_DIAG_BUILD
+#define ERM_DIAG_STOP(args, k) do { if ((args).dbg_stop == (k)) return; } while (0)
+#define ERM_DIAG_ON(args, k) ((args).dbg_stop == (k))
+#else
+#define ERM_DIAG_STOP(args, k) ((void)0)
+#define ERM_DIAG_ON(args, k) false
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Tiny step
 // ---------------------------------------------------------------------------------------------------------------------
@@ -154,7 +164,7 @@ struct TinyArgs {
     uint32_t chain; uint64_t seed; double k1, k2;
     int nq;               // number of small qr entries recorded per sweep
     int ngx;              // extra global statistics of slab0 (see PassArgs::ngx)
-    int dbg_stop;         // diagnostics only: return after stage k (0 = run everything)
+    int dbg_stop;         // -DERM_DIAG_BUILD only: return after stage k (0 = run everything); ignored by the shipped library
 };
 
 __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
@@ -691,7 +701,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
         reduce_rows(T.slab0, T.nb0, NS0, st0, tid, nthr);
         __syncthreads();
         stamp(1);
-        if (A.dbg_stop == 30) return;
+        ERM_DIAG_STOP(A, 30);
         const uint32_t prev_row = T.ctl->row;
         sweep = T.ctl->sweep + 1u;
         trow = T.first ? prev_row : prev_row + 1u;
@@ -718,7 +728,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
             for (int e = tid; e < nWaves * NG; e += nthr) sh_gacc[e] = 0.0;
         }
         __syncthreads();
-        if (A.dbg_stop == 31) return;
+        ERM_DIAG_STOP(A, 31);
         parsrc = lp;
     }
     const bool post_burn = trow >= A.ctl->burn_rows;
@@ -744,7 +754,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
     }
 
     stamp(2);
-    if (A.dbg_stop == 32) return;
+    ERM_DIAG_STOP(A, 32);
     if constexpr (FUSED) {
         if (wave == 0) {
             // structural chain of this sweep's tiny step on wave 0 while waves 1.. stream their row sums; its results (Sigma_p_t, beta_t,
@@ -783,7 +793,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
         ra = row0 + (long long)wave * rbase + (wave < rrem ? wave : rrem);
         rb = ra + rbase + (wave < rrem ? 1 : 0);
     }
-    if (A.dbg_stop == 1) return;
+    ERM_DIAG_STOP(A, 1);
 
     // =================================================================================================== phase 1 (i)
     // sums over each subject's items; lane (r, s): subject r of the group, items s, s+W, ...
@@ -831,7 +841,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
     }
     wave_sync();
     stamp(4);
-    if (A.dbg_stop == 5) return;
+    ERM_DIAG_STOP(A, 5);
 
     // =================================================================================================== phase 1 (ii)
     // one lane per subject: theta_t / zeta_t draws, per-subject outputs, structural log-likelihood, LatentQr's nu_{t+1}
@@ -962,7 +972,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
         }
     }
     stamp(6);
-    if (A.dbg_stop == 2) return;
+    ERM_DIAG_STOP(A, 2);
 
     // ---------------- omega_{t+1} | theta_t, a_t, b_t  (src/Draw.pl.jl:36-40), persistent lanes over the wave's flattened cells:
     // lane l owns cells l, l+64, l+128, ... of the slice (cell c = (subject ra + c / J, item c % J), which is also its offset in
@@ -992,7 +1002,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
         real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
         real* om = A.omega + (size_t)ra * J;
         const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
-        unsigned int n_att = 0, n_trip = 0;
+        [[maybe_unused]] unsigned int n_att = 0, n_trip = 0;
         // (letting a wave whose queue ran dry serve other waves' queues was tried: the hardware favours a SIMD's oldest wave, so the
         // four waves of a SIMD finish up to 17 us apart -- but the phase is VALU-throughput-bound, the SIMD is busy until the last
         // one ends either way, and the stealing logic only added instructions: 78.5 vs 75.3 us per sweep)
@@ -1023,7 +1033,11 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                 qhd[T] += n; qn[T] -= n;
             };
             while (__any(active)) {
-                ++n_trip; n_att += active ? 1u : 0u;
+#ifdef ERM_DIAG_BUILD
+    #ifdef ERM_DIAG_BUILD
+            ++n_trip; n_att += active ? 1u : 0u;
+#endif
+#endif
                 int piece = PG_NONE;
                 uint2 ent = make_uint2(0u, 0u);
                 if (active) {
@@ -1061,7 +1075,9 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
             for (int T = 0; T < 4; ++T) { if (qn[T] > 0) flush(T, qn[T]); }
         } else {
         while (__any(active)) {
+#ifdef ERM_DIAG_BUILD
             ++n_trip; n_att += active ? 1u : 0u;
+#endif
             if (active) {
                 uint32_t w0, w1, w2, w3;
                 philox4x32_10((uint32_t)(ra + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
@@ -1077,14 +1093,14 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
             }
         }
         }
-        if (A.dbg_stop == 9) {
+        if (ERM_DIAG_ON(A, 9)) {
             Ctl* cw = const_cast<Ctl*>(A.ctl);
             atomicAdd(&cw->dbg_attempts, (unsigned long long)n_att);
             if (lane == 0) { atomicAdd(&cw->dbg_trips, (unsigned long long)n_trip); atomicAdd(&cw->dbg_cells, (unsigned long long)ncell); }
         }
     }
     stamp(7);
-    if (A.dbg_stop == 3) return;
+    ERM_DIAG_STOP(A, 3);
     __syncthreads();
     stamp(8);
 
@@ -1138,7 +1154,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
     stamp(9);
     // =================================================================================================== phase 2
     // lane = item j; the waves stride over the workgroup's subjects; accumulators live in fp64 registers
-    for (int cb = 0; cb * 64 < J && A.dbg_stop != 7; ++cb) {
+    for (int cb = 0; cb * 64 < J && !ERM_DIAG_ON(A, 7); ++cb) {
         const int j = cb * 64 + lane;
         const bool jv = j < J;
         const real a = jv ? sh_a[j] : real(0), b = jv ? sh_b[j] : real(0);
@@ -1242,7 +1258,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
     }
 
     stamp(10);
-    if (A.dbg_stop == 4) return;
+    ERM_DIAG_STOP(A, 4);
 
     // ---------------- block epilogue: fixed-order reduction of the wave accumulators into this block's slab row
     ll = bfly_sum(ll, 1, 64);
@@ -1334,7 +1350,7 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
         T.tr_ll[prev_row] = llv;
     }
     if (T.mode == 1) return;
-    if (T.dbg_stop == 1) return;
+    ERM_DIAG_STOP(T, 1);
 
     tiny_draws<MODEL, STEP>(T, lp, st0, st1, part, work, sh_x, sweep);
     tiny_publish<MODEL, STEP>(T, lp, sweep, row, tid, TINY_THREADS);

@@ -165,6 +165,7 @@ template <typename real> struct Engine : EngineBase {
         if (graph_tail) (void)hipGraphExecDestroy(graph_tail);
         if (comm) (void)g_rccl.CommDestroy(comm);
         for (auto e : pass_ev) (void)hipEventDestroy(e);
+        if (host_ctl) (void)hipHostFree(host_ctl);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -230,6 +231,7 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&ev0));
         HIPCHK(hipEventCreate(&ev1));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 3 * sizeof(Ctl), hipHostMallocDefault));
 
         // ---- geometry: W lanes per subject
         if (cfg.lanes_per_row > 0) {
@@ -371,6 +373,28 @@ template <typename real> struct Engine : EngineBase {
         });
     }
 
+    // stage-timing knobs: read only by a -DERM_DIAG_BUILD library (the kernels of the shipped one contain no early return at all)
+    static int diag_stop(const char* name) {
+#ifdef ERM_DIAG_BUILD
+        const char* e = getenv(name);
+        return e ? atoi(e) : 0;
+#else
+        (void)name;
+        return 0;
+#endif
+    }
+    // subjects taken off wave 0's slice in a fused sweep (it runs the structural chain first).  The LDS caches are sized for
+    // skew >= 0 and at most a wave's share of the workgroup's rows: anything else is clamped.  ERM_SKEW is a tuning knob of the
+    // diagnostic build only.
+    int skew_rows() const {
+        int k = 2;
+#ifdef ERM_DIAG_BUILD
+        if (const char* e = getenv("ERM_SKEW")) k = atoi(e);
+#endif
+        const int nWaves = block_threads / 64;
+        const int cap = (int)std::max<int64_t>(0, rows_per_block / std::max(1, nWaves));
+        return std::min(std::max(k, 0), cap);
+    }
     PassArgs<real> pass_args(int phase, int mode, bool fz = false) const {
         PassArgs<real> a{};
         a.Y = dY.as<uint8_t>(); a.C = dC.as<real>(); a.omega = dOmega.as<real>(); a.nu = dNu.as<real>(); a.X = dX.as<real>();
@@ -383,12 +407,12 @@ template <typename real> struct Engine : EngineBase {
         a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
         a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
         a.N = N; a.rows_per_block = rows_per_block; a.rows_per_wave = rows_per_wave; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode; a.ngx = phase == 0 ? ngx() : 0;
-        { const char* e = getenv("ERM_SKEW"); a.skew = fz ? (e ? atoi(e) : 2) : 0; }
+        a.skew = fz ? skew_rows() : 0;
         a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
         if (!m_nu()) { a.k1 = 0.0; a.k2 = 1.0; }                                   // no quantile weights: nu == 1, k1 = 0, k2 = 1
-        { const char* e = getenv("ERM_PASS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
+        a.dbg_stop = diag_stop("ERM_PASS_STOP");
         a.dbg_ts = dDbgTs.as<unsigned long long>();
         a.row_base = (uint32_t)row_base;
         {   // the queues close the launch's dynamic LDS (8-byte aligned)
@@ -414,18 +438,20 @@ template <typename real> struct Engine : EngineBase {
         if (sharded()) {     // the statistics rows of all devices, gathered after every row pass; N = the whole data set
             t.slab0 = dShardRecv[0].as<double>(); t.slab1 = dShardRecv[1].as<double>(); t.nb0 = shard_count; t.nb1 = shard_count; t.N = n_total;
         }
-        { const char* e = getenv("ERM_TINY_STOP"); t.dbg_stop = e ? atoi(e) : 0; }
+        t.dbg_stop = diag_stop("ERM_TINY_STOP");
         return t;
     }
 
-    int64_t n_pass_timed = 0;
+    int64_t n_pass_timed = 0;                        // sweep-kernel launches inside event brackets in the current run
+    int64_t n_brackets = 0;                          // event pairs used
+    std::vector<int> bracket_launches;               // launches inside each bracket
     template <int MODEL, int PHASE> int launch_pass(int mode, bool timed) {
         PassArgs<real> a = pass_args(PHASE, mode);
         TinyArgs t{};
-        const bool ev = timed && cfg.profile && (size_t)(2 * n_pass_timed + 1) + 64 < pass_ev.size();
-        if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed], stream));
+        const bool ev = timed && cfg.profile && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size();
+        if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream));
         hipLaunchKernelGGL((pass_kernel<MODEL, real, PHASE, false>), dim3(grid_blocks), dim3(block_threads), lds_pass[PHASE], stream, a, t);
-        if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed + 1], stream)); ++n_pass_timed; }
+        if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; ++n_pass_timed; bracket_launches.push_back(1); }
         if (sharded()) return shard_exchange(PHASE, a.gslab);
         return 0;
     }
@@ -478,10 +504,10 @@ template <typename real> struct Engine : EngineBase {
     template <int MODEL> int launch_fused(bool first, bool timed) {
         PassArgs<real> a = pass_args(0, 1, true);
         TinyArgs t = tiny_args(0, first ? 1 : 0, true);
-        const bool ev = timed && cfg.profile && (size_t)(2 * n_pass_timed + 1) + 64 < pass_ev.size();
-        if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed], stream));
+        const bool ev = timed && cfg.profile && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size();
+        if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream));
         hipLaunchKernelGGL((pass_kernel<MODEL, real, 0, true>), dim3(grid_blocks), dim3(block_threads), fused_lds(), stream, a, t);
-        if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_pass_timed + 1], stream)); ++n_pass_timed; }
+        if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; ++n_pass_timed; bracket_launches.push_back(1); }
         cur ^= 1;
         if (sharded()) return shard_exchange(0, a.gslab);     // a.gslab: the group rows this launch wrote
         return 0;
@@ -512,20 +538,27 @@ template <typename real> struct Engine : EngineBase {
     }
     template <int MODEL> int build_graph(int nsw, hipGraphExec_t* out) {
         hipGraph_t g = nullptr;
-        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        const int cur0 = cur;                        // a fused sweep flips the double buffers while it is being captured: nsw is even, but a
+        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));       // failed capture must not leave the parity changed
         int rc = 0;
         for (int k = 0; k < nsw && !rc; ++k) rc = enqueue_sweep<MODEL>(false, false);
-        hipError_t e = hipStreamEndCapture(stream, &g);
-        if (rc) return rc;
-        HIPCHK(e);
-        HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
-        HIPCHK(hipGraphDestroy(g));
-        return 0;
+        const hipError_t e = hipStreamEndCapture(stream, &g);      // always ends the capture, also after a failed enqueue
+        if (!rc && e != hipSuccess) rc = fail(ERM_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        if (!rc) {
+            const hipError_t ei = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+            if (ei != hipSuccess) { *out = nullptr; rc = fail(ERM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+        }
+        if (g) (void)hipGraphDestroy(g);             // on every exit
+        if (rc) cur = cur0;
+        return rc;
     }
     template <int MODEL> int run_model(int64_t nsweeps) {
-        // prologue: omega_{t+1} (and nu_{t+1}) and the statistics of the current state
-        if (int rc = launch_pass<MODEL, 0>(0, false)) return rc;
-        if constexpr (fam_cq(MODEL)) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
+        // prologue: omega_{t+1} (and nu_{t+1}) and the statistics of the current state.  A run that CONTINUES the previous one finds both
+        // in place -- the last pass drew omega_{t+1} from the same addressed streams and left the same statistics -- and skips it.
+        if (!stats_valid) {
+            if (int rc = launch_pass<MODEL, 0>(0, false)) return rc;
+            if constexpr (fam_cq(MODEL)) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
+        }
         int64_t k = 0;
         if (nsweeps > 0) { if (int rc = enqueue_sweep<MODEL>(true, false)) return rc; k = 1; }
         // (a callback exchange synchronises with the host once per pass and cannot be captured; RCCL's all-gather is a stream operation)
@@ -551,26 +584,65 @@ template <typename real> struct Engine : EngineBase {
                 HIPCHK(hipGraphLaunch(graph_exec, stream));
             }
         }
-        if (use_graph && graph_tail && k >= 1) { for (; nsweeps - k >= TAIL_SWEEPS; k += TAIL_SWEEPS) HIPCHK(hipGraphLaunch(graph_tail, stream)); }
-        for (int64_t r = 0; k < nsweeps; ++k, ++r) { if (int rc = enqueue_sweep<MODEL>(false, (r % PROFILE_STRIDE) == 0)) return rc; }
-        if (int rc = launch_tiny<MODEL, 0>(1, nsweeps == 0)) return rc;
+        // a SHORT profiled run (a benchmark of a few dozen steps) brackets every one of its sweeps instead, so that the kernel time it
+        // reports is an average over the whole timed region, not one sample
+        // (fused models: in brackets of one replayed TAIL_SWEEPS-sweep graph each -- TAIL_SWEEPS launches of the sweep kernel and nothing else
+        // per event pair -- so that the benchmark still runs at graph-replay speed; the Cross family's sweeps hold tiny kernels too and are
+        // bracketed launch by launch)
+        const bool bracket_all = cfg.profile && nsweeps < 2 * block;
+        if (use_graph && graph_tail && k >= 1) {
+            const bool in_graph = bracket_all && !fam_cq(MODEL) && fused() && !sharded();
+            if (in_graph || !bracket_all) {
+                for (; nsweeps - k >= TAIL_SWEEPS; k += TAIL_SWEEPS) {
+                    const bool ev = in_graph && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size();
+                    if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream));
+                    HIPCHK(hipGraphLaunch(graph_tail, stream));
+                    if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; n_pass_timed += TAIL_SWEEPS; bracket_launches.push_back(TAIL_SWEEPS); }
+                }
+            }
+        }
+        for (int64_t r = 0; k < nsweeps; ++k, ++r) { if (int rc = enqueue_sweep<MODEL>(false, bracket_all || (r % PROFILE_STRIDE) == 0)) return rc; }
+        if (nsweeps > 0 || !stats_valid) { if (int rc = launch_tiny<MODEL, 0>(1, nsweeps == 0)) return rc; }
         return 0;
     }
 
+    // A run that fails after it has started enqueueing leaves the double buffers, the counters and the traces in an unknown state: the
+    // stream is drained, the buffer parity reset, and the engine refuses to continue until the caller installs a state again.
+    bool poisoned = false;
+    bool stats_valid = false;                        // omega_{t+1} (nu_{t+1}) and the statistics of the CURRENT state are resident (set by a completed run)
+    Ctl* host_ctl = nullptr;                         // pinned: [0] upload, [1], [2] read-back of the two device copies
+    bool has_stats_state() const { return host_ctl != nullptr; }
     int run(int64_t nsweeps) override {
         if (!has_data) return fail(ERM_ERR_STATE, "erm_set_data has not been called");
+        if (poisoned) return fail(ERM_ERR_STATE, "a previous erm_run failed part-way: call erm_set_state (and erm_reset_trace) before running again");
         if (nsweeps < 0) return fail(ERM_ERR_ARG, "nsweeps must be non-negative");
         if (rows_done + nsweeps > rows_cap) return fail(ERM_ERR_ARG, "trace capacity exceeded: n_iter*n_chain rows were allocated");
+        const int rc = run_checked(nsweeps);
+        if (rc != 0 && rc != ERM_ERR_NONFINITE) {
+            const std::string msg = g_err;            // keep the first error's message
+            (void)hipStreamSynchronize(stream);
+            (void)hipGetLastError();
+            cur = 0;
+            poisoned = true;
+            stats_valid = false;
+            g_err = msg;
+        }
+        return rc;
+    }
+    int run_checked(int64_t nsweeps) {
         HIPCHK(hipSetDevice(cfg.device));
-        Ctl c{};
+        if (sharded() || !has_stats_state()) stats_valid = false;
+        Ctl& c = host_ctl[0];                        // pinned: the uploads below are genuinely asynchronous
+        c = Ctl{};
         c.sweep = sweeps_total; c.row = (uint32_t)rows_done; c.burn_rows = (uint32_t)((int64_t)cfg.n_burnin * cfg.n_chain); c.err = 0;
         if (cur == 1) {      // every run starts from buffer 0 so that a captured graph always replays with the buffer parity it was built with
             HIPCHK(hipMemcpyAsync(dParB[0].p, dParB[1].p, dParB[0].bytes, hipMemcpyDeviceToDevice, stream));
+            if (stats_valid) HIPCHK(hipMemcpyAsync(dGslab0B[0].p, dGslab0B[1].p, dGslab0B[0].bytes, hipMemcpyDeviceToDevice, stream));
             cur = 0;
         }
         for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpyAsync(dCtlB[k].p, &c, sizeof(Ctl), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(dGcnt.p, 0, dGcnt.bytes, stream));
-        n_pass_timed = 0;
+        n_pass_timed = 0; n_brackets = 0; bracket_launches.clear();
         const bool calibrate = cfg.profile && pass_ev.size() >= 64 && !ev_calibrated;
         if (calibrate) {   // empty event pairs, once per engine: the bracketing overhead that is subtracted from every timed launch
             for (int k = 0; k < 16; ++k) { HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 2 - 2 * k], stream)); HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 1 - 2 * k], stream)); }
@@ -579,6 +651,7 @@ template <typename real> struct Engine : EngineBase {
         if (int rc = dispatch([&](auto m) -> int { return run_model<decltype(m)::value>(nsweeps); })) return rc;
         HIPCHK(hipEventRecord(ev1, stream));
         HIPCHK(hipGetLastError());
+        for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpyAsync(&host_ctl[1 + k], dCtlB[k].p, sizeof(Ctl), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -590,18 +663,15 @@ template <typename real> struct Engine : EngineBase {
         }
         const double null_ms = ev_null_ms;
         timing.event_overhead_ms = null_ms;
-        for (int64_t k = 0; k < n_pass_timed; ++k) {
+        for (int64_t k = 0; k < n_brackets; ++k) {   // a bracket holds 1 launch, or the TAIL_SWEEPS launches of one replayed graph
             float t = 0.f;
             HIPCHK(hipEventElapsedTime(&t, pass_ev[2 * k], pass_ev[2 * k + 1]));
             timing.pass_ms_total += std::max(0.0, (double)t - null_ms);
         }
-        Ctl back{}, back0{};
-        HIPCHK(hipMemcpy(&back, dCtlB[cur].p, sizeof(Ctl), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&back0, dCtlB[0].p, sizeof(Ctl), hipMemcpyDeviceToHost));
-        back.err = back0.err;
-        {   // the diagnostic counters (ERM_PASS_STOP=9) accumulate in whichever buffer a launch read: add the other one
-            Ctl b1{};
-            HIPCHK(hipMemcpy(&b1, dCtlB[1 - cur].p, sizeof(Ctl), hipMemcpyDeviceToHost));
+        Ctl back = host_ctl[1 + cur];
+        back.err = host_ctl[1].err;                  // the sticky flag lives in buffer 0
+        {   // the diagnostic counters (ERM_PASS_STOP=9 of a diagnostic build) accumulate in whichever buffer a launch read: add the other one
+            const Ctl& b1 = host_ctl[1 + (1 - cur)];
             back.dbg_attempts += b1.dbg_attempts; back.dbg_trips += b1.dbg_trips; back.dbg_cells += b1.dbg_cells;
         }
         const int64_t burn = (int64_t)cfg.n_burnin * cfg.n_chain;
@@ -609,7 +679,7 @@ template <typename real> struct Engine : EngineBase {
         if (hi > lo) post_rows += hi - lo;
         rows_done += nsweeps;
         sweeps_total += (uint32_t)nsweeps;
-        if (getenv("ERM_PASS_STOP") && atoi(getenv("ERM_PASS_STOP")) == 9)
+        if (diag_stop("ERM_PASS_STOP") == 9)
             fprintf(stderr, "[erm dbg] attempts %llu cells %llu wave-trips %llu -> attempts/cell %.4f, lane efficiency %.4f\n", back.dbg_attempts, back.dbg_cells, back.dbg_trips,
                     (double)back.dbg_attempts / (double)back.dbg_cells, (double)back.dbg_attempts / (64.0 * (double)back.dbg_trips));
         if (dDbgTs.p) {      // per-wave phase timeline of the LAST launch (us since the workgroup's first stamp)
@@ -629,6 +699,7 @@ template <typename real> struct Engine : EngineBase {
                 }
             }
         }
+        stats_valid = back.err == 0;
         if (back.err) {
             const int e = (int)back.err - 1;
             const char* names[] = {"a", "b", "lambda", "sig2t", "rho"};
@@ -722,6 +793,7 @@ template <typename real> struct Engine : EngineBase {
         }
         HIPCHK(hipMemcpy(dCst.p, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
         has_data = true;
+        stats_valid = false;
         return 0;
     }
 
@@ -828,6 +900,7 @@ template <typename real> struct Engine : EngineBase {
         }
         HIPCHK(hipMemcpy(dCst.p, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
         has_data = true;
+        stats_valid = false;
         return 0;
     }
     // the resident data set back in the caller's (column-major) layout: Y bytes, logT = centred value + column mean, X
@@ -883,6 +956,8 @@ template <typename real> struct Engine : EngineBase {
         if (!st) return fail(ERM_ERR_ARG, "state is NULL");
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamSynchronize(stream));
+        poisoned = false;
+        stats_valid = false;
         std::vector<double> par(par_size(J));
         HIPCHK(hipMemcpy(par.data(), dParB[cur].p, par.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (st->a) memcpy(&par[0], st->a, J * sizeof(double));
@@ -918,6 +993,7 @@ template <typename real> struct Engine : EngineBase {
 
     int get_state(erm_state* st) override {
         if (!st) return fail(ERM_ERR_ARG, "state is NULL");
+        if (poisoned) return fail(ERM_ERR_STATE, "a previous erm_run failed part-way: the state is undefined until erm_set_state");
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamSynchronize(stream));
         std::vector<double> par(par_size(J));

@@ -35,7 +35,7 @@ class _GibbsBase:
     _has_intercept = True
 
     def __init__(self, Cond: SimConditions, *, Data=None, truePara=None, Para=None, Post=None,
-                 seed=1234, device=0, precision="f32", trace="full", chain_id=0, shard=None, **engine_opts):
+                 seed=1234, device=0, precision="f64", trace="full", chain_id=0, shard=None, **engine_opts):
         self.Cond = Cond
         self.Data = Data
         self.truePara = truePara

@@ -63,7 +63,7 @@ for (T, model) in ((:GibbsMlIrt, MODEL_MLIRT), (:GibbsRtIrt, MODEL_RTIRT), (:Gib
             shard::Any      # nothing, or (rank, count, nSubjTotal, rowBase, uid): Cond.nSubj / Data then describe this process's subjects only
                             # (give every rank the same β / ρ / Σp start, e.g. Random.seed!(s) before the constructor and cut θ, ζ afterwards:
                             #  setInitialValues draws them from the global RNG as the reference does)
-            function $T(Cond; Data = [], truePara = [], Para = Float64[], Post = Float64[], seed = 1234, device = 0, precision = 0, shard = nothing)
+            function $T(Cond; Data = [], truePara = [], Para = Float64[], Post = Float64[], seed = 1234, device = 0, precision = 1, shard = nothing)
                 obj = new(Cond, Data, truePara, Para, Post, C_NULL, nothing, UInt64(seed), Int32(device), Int32(precision), shard)
                 setInitialValues(obj)                      # always overwrites Para, as the reference's constructors do
                 obj.Post = OutputPost([], [], [], [], Float64[])

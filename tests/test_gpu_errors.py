@@ -94,3 +94,51 @@ def test_a_poisoned_state_is_reported_not_propagated():
     e.set_state(theta=np.full(200, np.nan))
     with pytest.raises(L.ErmError, match="non-finite parameter"):
         e.run(4)
+
+
+def test_stage_timing_knobs_do_not_exist_in_the_shipped_library(monkeypatch):
+    """ERM_PASS_STOP / ERM_TINY_STOP / ERM_SKEW are stage-timing knobs of a -DERM_DIAG_BUILD library (tools/tiny_stages.sh): early returns
+    that leave garbage results.  The shipped library compiles none of that code, so a variable left exported cannot touch a fit."""
+    Y, logT, X, init, _ = pu.make_problem("rtirt", 700, 9)
+    ref = pu.run_device("rtirt", Y, logT, X, init, 6, precision="f64")
+    for name, val in (("ERM_PASS_STOP", "3"), ("ERM_PASS_STOP", "9"), ("ERM_TINY_STOP", "1"), ("ERM_SKEW", "-7"), ("ERM_SKEW", "100000")):
+        monkeypatch.setenv(name, val)
+        for prec in ("f64", "f32"):
+            got = pu.run_device("rtirt", Y, logT, X, init, 6, precision=prec)
+            if prec == "f64":
+                assert np.array_equal(got["ra"], ref["ra"]) and np.array_equal(got["item"], ref["item"]) and np.array_equal(got["ll"], ref["ll"]), (name, val)
+            else:
+                assert np.all(np.isfinite(got["ra"])) and np.max(np.abs(got["item"] - ref["item"])) < 5e-2, (name, val)
+        monkeypatch.delenv(name)
+
+
+def test_a_failed_run_poisons_the_engine_until_a_state_is_installed():
+    """erm_run failing part-way (here: the shard exchange callback raising on its second call) must not leave the double buffers in
+    an unknown parity silently: the engine refuses erm_run / erm_get_state until erm_set_state."""
+    Y, logT, X, init, _ = pu.make_problem("rtirt", 300, 6)
+    eng = L.Engine(model=pu.MODELS["rtirt"], n_item=6, n_subj=300, n_feat=3, n_iter=8, n_chain=1, n_burnin=4, cov2one=1, q_rt=0.85, seed=1234, precision=1, trace_mode=1)
+    lib = L.load()
+    calls = {"n": 0, "fail_at": None}
+
+    def exchange(send, recv, nbytes):          # a one-shard "all-gather": copy send -> recv
+        calls["n"] += 1
+        if calls["fail_at"] is not None and calls["n"] >= calls["fail_at"]:
+            raise RuntimeError("link down")
+        assert lib.erm_copy(recv, send, nbytes) == 0
+    eng.set_shard(0, 1, 300, 0, exchange)
+    eng.set_data(Y, logT, X)
+    st = {("lambda_" if k == "lam" else k): v for k, v in init.items()}
+    eng.set_state(**st)
+    eng.run(2)
+    calls["fail_at"] = calls["n"] + 2
+    with pytest.raises(L.ErmError, match="exchange"):
+        eng.run(3)
+    with pytest.raises(L.ErmError, match="failed part-way"):
+        eng.run(1)
+    with pytest.raises(L.ErmError, match="failed part-way"):
+        eng.get_state()
+    calls["fail_at"] = None
+    eng.set_state(**st)
+    eng.reset_trace()
+    eng.run(2)
+    assert np.all(np.isfinite(eng.item_trace()))

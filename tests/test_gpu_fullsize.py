@@ -53,3 +53,60 @@ def test_fullsize_other_models_run_clean(model):
     m = r["engine"].get_mean()
     assert np.sqrt(np.mean((m["b"] - tp.b) ** 2)) < 0.1
     assert np.corrcoef(m["theta"], tp.theta)[0, 1] > 0.9
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: GibbsRtIrt nSubj = 500000, nItem = 100 (one chain's load on one GPU).  The working set (Y 50 MB, logT and
+# omega 200 / 400 MB each) no longer fits the 256 MiB Infinity Cache, a workgroup owns ~1950 subjects x 100 items and the LDS layout
+# grows with nItem -- a regime of its own for the engine.
+# ------------------------------------------------------------------------------------------------------------------------------
+N4, J4 = 500_000, 100
+
+
+@pytest.fixture(scope="module")
+def rtirt4():
+    return pu.make_problem("rtirt", N4, J4, 3, seed=4321, qRt=0.5)
+
+
+def test_configs4_f64_one_sweep_matches_oracle(rtirt4):
+    Y, logT, X, init, _ = rtirt4
+    dev = pu.run_device("rtirt", Y, logT, X, init, 1, precision="f64", qRt=0.5, n_burnin=0)
+    pu.oracle().orc_set_threads(16)                      # the oracle's OpenMP mode: bit-identical to its single-thread run (test_oracle_sweeps.py)
+    try:
+        tr = pu.OracleProblem("rtirt", Y, logT, X, init, qRt=0.5).run(1)
+    finally:
+        pu.oracle().orc_set_threads(1)
+    assert pu.rel_err(dev["ra"][:, :, 0], tr["ra"]).max() < 1e-8
+    assert pu.rel_err(dev["rt"][:, :, 0], tr["rt"]).max() < 1e-8
+    assert pu.rel_err(dev["qr"][:, :, 0], tr["qr"]).max() < 1e-8
+    assert pu.rel_err(dev["ll"][:, 0, 0], tr["ll"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_configs4_reproducible_continuable_geometry_invariant_and_recovers_truth(rtirt4, precision):
+    Y, logT, X, init, tp = rtirt4
+    T = 60
+    a = pu.run_device("rtirt", Y, logT, X, init, T, precision=precision, qRt=0.5, trace_full=False)
+    assert np.all(np.isfinite(a["item"])) and np.all(np.isfinite(a["ll"]))
+    b = pu.run_device("rtirt", Y, logT, X, init, T, precision=precision, qRt=0.5, trace_full=False)
+    assert np.array_equal(a["item"], b["item"]) and np.array_equal(a["ll"], b["ll"])              # bit-reproducible
+    # run(x) + run(y) == run(x + y)
+    L = pu.ge.load_package()._lib
+    eng = L.Engine(model=pu.MODELS["rtirt"], n_item=J4, n_subj=N4, n_feat=3, n_iter=T, n_chain=1, n_burnin=T // 2, cov2one=1, q_rt=0.5, seed=1234,
+                   precision={"f32": 0, "f64": 1}[precision], trace_mode=0)
+    eng.set_data(Y, logT, X)
+    eng.set_state(**init)
+    for n in (T // 3, T - T // 3 - 5, 5):
+        eng.run(n)
+    assert np.array_equal(eng.item_trace(), a["item"]) and np.array_equal(eng.trace(L.TRACE_LOGLIKE), a["ll"])
+    ma, me = a["engine"].get_mean(), eng.get_mean()
+    assert np.array_equal(ma["theta"], me["theta"]) and np.array_equal(ma["zeta"], me["zeta"])
+    del eng, b
+    # another launch geometry changes only the summation order of the statistics
+    g = pu.run_device("rtirt", Y, logT, X, init, 8, precision=precision, qRt=0.5, trace_full=False, lanes_per_row=16, block_threads=512, grid_blocks=300)
+    tol = 2e-4 if precision == "f32" else 1e-9
+    assert np.max(np.abs(a["item"][:8] - g["item"]) / np.maximum(np.abs(a["item"][:8]), 1.0)) < tol
+    # recovery of the generating values (README.md:61-77 style)
+    assert np.sqrt(np.mean((ma["a"] - tp.a) ** 2)) < 0.02 and np.sqrt(np.mean((ma["b"] - tp.b) ** 2)) < 0.02
+    assert np.max(np.abs(ma["sig2t"] / tp.sig2t - 1)) < 0.12 and np.corrcoef(ma["sig2t"], tp.sig2t)[0, 1] > 0.99
+    assert np.corrcoef(ma["theta"], tp.theta)[0, 1] > 0.95 and np.corrcoef(ma["zeta"], tp.zeta)[0, 1] > 0.99

@@ -147,14 +147,22 @@ def test_teacher_forced(model, precision, tol):
 
 @pytest.mark.parametrize("model", ["mlirt", "rtirt", "latentqr", "null", "cross", "latent"])
 def test_f32_chain_stays_coupled(model):
-    T = 60
+    """fp32 engine against the oracle's fp64 chain on the same addressed variates.  Tolerance: the posterior means of
+    every item-level parameter within 3 Monte-Carlo standard errors, each standard error taken from the ORACLE chain (sd of its
+    post-burn-in draws / sqrt(ESS), the package's split-chain Geyer estimator)."""
+    T = 80
     res = pu.run_pair(model, N=1500, J=20, nsweeps=T, precision="f32")
     N = 1500
-    d, o = res["dev_ra"][T // 2:, N:].mean(0), res["orc"]["ra"][T // 2:, N:].mean(0)
-    assert np.max(np.abs(d - o)) < 5e-3
+    ess_rhat = pu.ge.load_package().gibbs.ess_rhat
+
+    def check(dev, orc):
+        post = orc[T // 2:]
+        se = np.array([post[:, k].std(ddof=1) / np.sqrt(min(max(ess_rhat(post[:, k])[0], 1.0), post.shape[0])) for k in range(post.shape[1])])
+        z = np.abs(dev[T // 2:].mean(0) - post.mean(0)) / se
+        assert z.max() < 3.0, (model, z.max())
+    check(res["dev_ra"][:, N:], res["orc"]["ra"][:, N:])
     if model != "mlirt":
-        d, o = res["dev_rt"][T // 2:, N:].mean(0), res["orc"]["rt"][T // 2:, N:].mean(0)
-        assert np.max(np.abs(d - o) / np.maximum(np.abs(o), 1.0)) < 5e-3
+        check(res["dev_rt"][:, N:], res["orc"]["rt"][:, N:])
     assert np.max(np.abs(res["dev_ll"] - res["orc"]["ll"]) / np.abs(res["orc"]["ll"])) < 1e-3
 
 
