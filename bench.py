@@ -59,6 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--cpu-sweeps", type=int, default=-1, help="oracle sweeps for cpu_baseline (-1 = auto ~15 s, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket sweep-kernel launches with HIP events")
+    ap.add_argument("--clock-warmup-ms", type=float, default=300.0, help="after the W warm-up steps, keep the GPU busy with further UNTIMED sweeps of the same engine for "
+                                                                         "this long before the timed region (a few ms of work do not bring an idle MI355X to its sustained clock; 0 = off)")
     ap.add_argument("--shard-exchange", default="rccl", choices=["rccl", "callback"], help="--shard: in-stream RCCL all-gather (default) or the "
                                                         "host callback over torch.distributed")
     ap.add_argument("--shard", action="store_true", help="NOT the headline: ONE chain of --nsubj subjects sharded over the ranks (strong scaling; "
@@ -214,12 +216,21 @@ def measure(pkg, ge_mod, torch, dist, args, model, N, J, F, precision, data, st,
 
     if args.warmup > 0:
         eng.run(args.warmup)
+    spun = 0
+    if args.clock_warmup_ms > 0:        # untimed: the chain simply continues (its trace rows are recycled), so the timed steps start from a busy device
+        t_end = time.perf_counter() + args.clock_warmup_ms * 1e-3
+        while time.perf_counter() < t_end:
+            eng.reset_trace()
+            eng.run(min(rows, 64))
+            spun += min(rows, 64)
+        eng.reset_trace()
     barrier()
     t0 = time.perf_counter()
     eng.run(args.steps)            # erm_run returns after hipStreamSynchronize on the engine's stream
     barrier()
     dt = time.perf_counter() - t0
     tm = eng.timing()
+    tm["clock_warmup_sweeps"] = spun
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -356,6 +367,7 @@ def main():
                        "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"], "ranks": world, "collective_backend": backend,
                        "rccl_ranks": world if backend == "nccl" else 0},
             "sweeps_per_s": args.steps * (1 if shard else world) / dt, "device_ms_per_step": tm["run_ms"] / args.steps,
+            "untimed_clock_warmup": {"ms": args.clock_warmup_ms, "sweeps": tm["clock_warmup_sweeps"], "note": "further untimed sweeps of the same chain between the W warm-up steps and the timed region"},
         }
         if gather_ms is not None:
             out["gather_ms"] = gather_ms

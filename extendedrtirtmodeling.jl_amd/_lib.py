@@ -23,6 +23,8 @@ EXPORTS = [
     "erm_reset_trace", "erm_trace_width", "erm_get_trace", "erm_item_trace_width", "erm_get_item_trace", "erm_get_mean",
     "erm_post_count", "erm_get_diagnostics", "erm_simulate_data", "erm_get_truth", "erm_get_data", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample", "erm_sample_gig",
     "erm_set_shard", "erm_copy", "erm_rccl_unique_id", "erm_set_shard_rccl",
+    "erm_farm_create", "erm_farm_destroy", "erm_farm_chains", "erm_farm_engine", "erm_farm_set_data", "erm_farm_set_state", "erm_farm_get_state",
+    "erm_farm_run", "erm_farm_reset_trace", "erm_farm_get_trace", "erm_farm_get_mean", "erm_farm_post_count", "erm_farm_used_rccl",
 ]
 
 
@@ -104,6 +106,23 @@ def load():
     lib.erm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.erm_rccl_unique_id.argtypes = [C.c_void_p]
     lib.erm_set_shard_rccl.argtypes = [H, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+    lib.erm_farm_create.argtypes = [C.POINTER(erm_config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(H)]
+    lib.erm_farm_destroy.argtypes = [H]
+    lib.erm_farm_destroy.restype = None
+    lib.erm_farm_chains.argtypes = [H]
+    lib.erm_farm_chains.restype = C.c_int32
+    lib.erm_farm_engine.argtypes = [H, C.c_int32]
+    lib.erm_farm_engine.restype = H
+    lib.erm_farm_set_data.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.erm_farm_set_state.argtypes = [H, C.c_int32, C.POINTER(erm_state)]
+    lib.erm_farm_get_state.argtypes = [H, C.c_int32, C.POINTER(erm_state)]
+    lib.erm_farm_run.argtypes = [H, C.c_int64]
+    lib.erm_farm_reset_trace.argtypes = [H]
+    lib.erm_farm_get_trace.argtypes = [H, C.c_int, C.c_void_p]
+    lib.erm_farm_get_mean.argtypes = [H, C.POINTER(erm_state)]
+    lib.erm_farm_post_count.argtypes = [H]
+    lib.erm_farm_post_count.restype = C.c_int64
+    lib.erm_farm_used_rccl.argtypes = [H]
     _lib = lib
     return lib
 
@@ -281,6 +300,114 @@ class Engine:
         t = erm_timing()
         check(self._lib.erm_get_timing(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in erm_timing._fields_}
+
+
+class _Borrowed(Engine):
+    """A farm's engine seen through the Engine wrapper (owned by the farm: never destroyed from here)."""
+
+    def __init__(self, lib, handle, cfg):
+        self._lib, self._h, self.cfg = lib, handle, cfg
+
+    def close(self):
+        self._h = None
+
+
+class Farm:
+    """erm_farm_*: nChain independent chains, chain l on device devices[l] (include/ertirt.h).  The chains sample concurrently on host
+    threads of the library; get_mean() is the one collective (RCCL all-reduce over the devices)."""
+
+    def __init__(self, devices, **kw):
+        lib = load()
+        cfg = erm_config()
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown config field {k}")
+            setattr(cfg, k, v)
+        self.cfg, self._lib = cfg, lib
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        check(lib.erm_farm_create(C.byref(cfg), arr, len(self.devices), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.erm_farm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_chains(self):
+        return int(self._lib.erm_farm_chains(self._h))
+
+    def engine(self, chain: int):
+        h = self._lib.erm_farm_engine(self._h, int(chain))
+        if not h:
+            raise ErmError("no such chain")
+        c = erm_config.from_buffer_copy(self.cfg)
+        c.n_chain, c.chain_id, c.device = 1, int(chain), self.devices[chain]
+        return _Borrowed(self._lib, C.c_void_p(h), c)
+
+    def set_data(self, Y, logT=None, X=None):
+        Ya = np.asarray(Y)
+        if Ya.dtype != np.bool_ and not np.all((Ya == 0) | (Ya == 1)):
+            raise ValueError("Y must contain only 0/1")
+        Yf = np.asfortranarray(Ya.astype(np.uint8))
+        lt = None if logT is None else np.asfortranarray(logT, dtype=np.float64)
+        xx = None if X is None or np.size(X) == 0 else np.asfortranarray(X, dtype=np.float64)
+        check(self._lib.erm_farm_set_data(self._h, Yf.ctypes.data, None if lt is None else lt.ctypes.data, None if xx is None else xx.ctypes.data))
+
+    def set_state(self, chain: int, **arrays):
+        arrs = {k: (None if v is None else np.asfortranarray(v, dtype=np.float64)) for k, v in arrays.items()}
+        st, keep = state_struct(arrs)
+        check(self._lib.erm_farm_set_state(self._h, int(chain), C.byref(st)))
+
+    def get_state(self, chain: int):
+        bufs = self.engine(chain)._state_buffers()
+        st, keep = state_struct(bufs)
+        check(self._lib.erm_farm_get_state(self._h, int(chain), C.byref(st)))
+        return bufs
+
+    def run(self, nsweeps: int):
+        check(self._lib.erm_farm_run(self._h, int(nsweeps)))
+
+    def reset_trace(self):
+        check(self._lib.erm_farm_reset_trace(self._h))
+
+    @property
+    def post_count(self):
+        return int(self._lib.erm_farm_post_count(self._h))
+
+    @property
+    def used_rccl(self):
+        return bool(self._lib.erm_farm_used_rccl(self._h))
+
+    def get_mean(self):
+        bufs = self.engine(0)._state_buffers()
+        st, keep = state_struct(bufs)
+        check(self._lib.erm_farm_get_mean(self._h, C.byref(st)))
+        return bufs
+
+    def item_trace(self):
+        """Item-level trace rows in the single-engine order (row m * nChain + l = iteration m of chain l)."""
+        per = [self.engine(l).item_trace() for l in range(self.n_chains)]
+        out = np.empty((per[0].shape[0] * len(per), per[0].shape[1]), dtype=np.float64)
+        for l, t in enumerate(per):
+            out[l::len(per)] = t
+        return out
+
+    def trace(self, which: int):
+        """Post.ra / rt / qr / logLike as (nIter, width, nChain), chain l in slab l."""
+        w = int(self._lib.erm_trace_width(self._lib.erm_farm_engine(self._h, 0), which))
+        if w <= 0:
+            return np.zeros((0,), dtype=np.float64)
+        out = np.empty((self.cfg.n_iter, w, self.n_chains), dtype=np.float64, order="F")
+        check(self._lib.erm_farm_get_trace(self._h, which, out.ctypes.data))
+        return out
 
 
 def rccl_unique_id() -> bytes:

@@ -1374,6 +1374,12 @@ __global__ void __launch_bounds__(256) shard_pack_kernel(const double* gslab, in
     reduce_rows(gslab, nb, NS, out, (int)threadIdx.x, (int)blockDim.x);
 }
 
+// dst[i] += src[i] (chain farms: post-burn-in sums of the chains that share a device, before the RCCL all-reduce over the devices)
+__global__ void __launch_bounds__(256) acc_kernel(double* dst, const double* src, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
 template <typename T>
 __global__ void diag_kernel(const T* tr, long long ncol, long long ld, int nIter, int nChain, int nBurnin, double* ess, double* rhat)
 {

@@ -10,6 +10,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 #include "ertirt.h"
@@ -37,6 +38,10 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::mutex mu;
@@ -50,9 +55,13 @@ struct Rccl {
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString) { lib = nullptr; return fail(ERM_ERR_STATE, "RCCL library lacks an expected symbol"); }
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString || !AllReduce || !CommInitAll || !GroupStart || !GroupEnd) { lib = nullptr; return fail(ERM_ERR_STATE, "RCCL library lacks an expected symbol"); }
         return 0;
     }
 };
@@ -94,6 +103,11 @@ struct EngineBase {
     virtual int get_truth(double*, double*) = 0;
     virtual int reset_trace() = 0;
     virtual int set_shard(int, int, int64_t, int64_t, erm_exchange_fn, void*, const void*) = 0;
+    // chain farms (erm_farm_*): this chain's post-burn-in SUMS [item-level trace columns | theta | zeta | nu] added into `acc` (device memory
+    // of this engine's device, summary_len() doubles), and the inverse step from a vector of means to an erm_state
+    virtual int64_t summary_len() const = 0;
+    virtual int summary_add(double* acc) = 0;
+    virtual int summary_unpack(const double* mean, erm_state* out) const = 0;
     int64_t rows_done = 0;
     int64_t post_rows = 0;
     erm_timing timing{};
@@ -163,6 +177,7 @@ template <typename real> struct Engine : EngineBase {
     ~Engine() override {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (graph_tail) (void)hipGraphExecDestroy(graph_tail);
+        if (graph_mid) (void)hipGraphExecDestroy(graph_mid);
         if (comm) (void)g_rccl.CommDestroy(comm);
         for (auto e : pass_ev) (void)hipEventDestroy(e);
         if (host_ctl) (void)hipHostFree(host_ctl);
@@ -524,7 +539,8 @@ template <typename real> struct Engine : EngineBase {
     static constexpr int GRAPH_SWEEPS = 32;
     static constexpr int PROFILE_STRIDE = 8;
     static constexpr int TAIL_SWEEPS = 4;            // a second, short graph for the remainder of a run (both counts are even: buffer parity)
-    hipGraphExec_t graph_exec = nullptr, graph_tail = nullptr;
+    static constexpr int MID_SWEEPS = 16;            // profile mode: the bracketed unit of a short run (a benchmark of a few dozen steps)
+    hipGraphExec_t graph_exec = nullptr, graph_tail = nullptr, graph_mid = nullptr;
     bool ev_calibrated = false; double ev_null_ms = 0.0;
     template <int MODEL> int enqueue_sweep(bool first, bool timed) {
         if constexpr (!fam_cq(MODEL)) { if (fused()) return launch_fused<MODEL>(first, timed); }
@@ -574,6 +590,7 @@ template <typename real> struct Engine : EngineBase {
         if (use_graph && !graph_exec && k == 1 && (cfg.profile || nsweeps - k >= block)) {
             if (int rc = build_graph<MODEL>(GRAPH_SWEEPS, &graph_exec)) return rc;
             if (int rc = build_graph<MODEL>(TAIL_SWEEPS, &graph_tail)) return rc;
+            if (cfg.profile) { if (int rc = build_graph<MODEL>(MID_SWEEPS, &graph_mid)) return rc; }
         }
         if (use_graph && nsweeps - k >= block) {
             for (; nsweeps - k >= block; k += block) {
@@ -593,12 +610,15 @@ template <typename real> struct Engine : EngineBase {
         if (use_graph && graph_tail && k >= 1) {
             const bool in_graph = bracket_all && !fam_cq(MODEL) && fused() && !sharded();
             if (in_graph || !bracket_all) {
-                for (; nsweeps - k >= TAIL_SWEEPS; k += TAIL_SWEEPS) {
+                auto replay = [&](hipGraphExec_t g, int nsw) -> int {
                     const bool ev = in_graph && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size();
                     if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream));
-                    HIPCHK(hipGraphLaunch(graph_tail, stream));
-                    if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; n_pass_timed += TAIL_SWEEPS; bracket_launches.push_back(TAIL_SWEEPS); }
-                }
+                    HIPCHK(hipGraphLaunch(g, stream));
+                    if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; n_pass_timed += nsw; bracket_launches.push_back(nsw); }
+                    return 0;
+                };
+                if (in_graph && graph_mid) { for (; nsweeps - k >= MID_SWEEPS; k += MID_SWEEPS) { if (int rc = replay(graph_mid, MID_SWEEPS)) return rc; } }
+                for (; nsweeps - k >= TAIL_SWEEPS; k += TAIL_SWEEPS) { if (int rc = replay(graph_tail, TAIL_SWEEPS)) return rc; }
             }
         }
         for (int64_t r = 0; k < nsweeps; ++k, ++r) { if (int rc = enqueue_sweep<MODEL>(false, bracket_all || (r % PROFILE_STRIDE) == 0)) return rc; }
@@ -1159,6 +1179,30 @@ template <typename real> struct Engine : EngineBase {
         return 0;
     }
 
+    // sums over the post-burn-in rows of the item-level trace columns (a, b, lambda, sig2t, small part of qr)
+    int item_sums(std::vector<double>& m) {
+        std::vector<double> it;
+        if (int rc = fetch_item_trace(it)) return rc;
+        const int64_t wi = item_trace_width(), burn = (int64_t)cfg.n_burnin * cfg.n_chain;
+        m.assign(wi, 0.0);
+        for (int64_t r = burn; r < rows_done; ++r) for (int64_t k = 0; k < wi; ++k) m[k] += it[r * wi + k];
+        return 0;
+    }
+    // item-level means -> the fields of Post.mean (src/GibbsRtIrt.pl.jl:249-254, 327-343; Cross :304-318; Latent :316-330)
+    void unpack_items(const double* m, erm_state* out) const {
+        if (out->a) memcpy(out->a, &m[0], J * sizeof(double));
+        if (out->b) memcpy(out->b, &m[J], J * sizeof(double));
+        if (out->lambda) memcpy(out->lambda, &m[2 * J], J * sizeof(double));
+        if (out->sig2t) memcpy(out->sig2t, &m[3 * J], J * sizeof(double));
+        const double* q = &m[4 * J];
+        switch (cfg.model) {
+        case ERM_MODEL_MLIRT: if (out->beta) memcpy(out->beta, q, (F + 1) * sizeof(double)); break;
+        case ERM_MODEL_RTIRT: if (out->beta) memcpy(out->beta, q, 2 * (F + 1) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + 2 * (F + 1), 4 * sizeof(double)); break;
+        case ERM_MODEL_CROSSQR: case ERM_MODEL_CROSS: if (out->rho) memcpy(out->rho, q, J * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + J, 4 * sizeof(double)); break;
+        case ERM_MODEL_NULL: if (out->beta) memset(out->beta, 0, 2 * (F + 1) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + 2, 4 * sizeof(double)); break;
+        default: if (out->beta) memcpy(out->beta, q, (F + 2) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + F + 2, 4 * sizeof(double));
+        }
+    }
     int get_mean(erm_state* out) override {
         if (!out) return fail(ERM_ERR_ARG, "state is NULL");
         HIPCHK(hipSetDevice(cfg.device));
@@ -1178,23 +1222,44 @@ template <typename real> struct Engine : EngineBase {
             if (cfg.model == ERM_MODEL_LATENTQR) { if (int rc = subj(dSumNu, out->nu, N, false)) return rc; }
             else if (int rc = subj(dSumNu, out->nu, (size_t)N * J, true)) return rc;
         }
-        std::vector<double> it;
-        if (int rc = fetch_item_trace(it)) return rc;
-        const int64_t wi = item_trace_width(), burn = (int64_t)cfg.n_burnin * cfg.n_chain;
-        std::vector<double> m(wi, 0.0);
-        for (int64_t r = burn; r < rows_done; ++r) for (int64_t k = 0; k < wi; ++k) m[k] += it[r * wi + k];
+        std::vector<double> m;
+        if (int rc = item_sums(m)) return rc;
         for (auto& v : m) v *= inv;
-        if (out->a) memcpy(out->a, &m[0], J * sizeof(double));
-        if (out->b) memcpy(out->b, &m[J], J * sizeof(double));
-        if (out->lambda) memcpy(out->lambda, &m[2 * J], J * sizeof(double));
-        if (out->sig2t) memcpy(out->sig2t, &m[3 * J], J * sizeof(double));
-        const double* q = &m[4 * J];
-        switch (cfg.model) {
-        case ERM_MODEL_MLIRT: if (out->beta) memcpy(out->beta, q, (F + 1) * sizeof(double)); break;
-        case ERM_MODEL_RTIRT: if (out->beta) memcpy(out->beta, q, 2 * (F + 1) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + 2 * (F + 1), 4 * sizeof(double)); break;
-        case ERM_MODEL_CROSSQR: case ERM_MODEL_CROSS: if (out->rho) memcpy(out->rho, q, J * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + J, 4 * sizeof(double)); break;
-        case ERM_MODEL_NULL: if (out->beta) memset(out->beta, 0, 2 * (F + 1) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + 2, 4 * sizeof(double)); break;
-        default: if (out->beta) memcpy(out->beta, q, (F + 2) * sizeof(double)); if (out->sigp) memcpy(out->sigp, q + F + 2, 4 * sizeof(double));
+        unpack_items(m.data(), out);
+        return 0;
+    }
+
+    // ---- chain farms: [item sums (wi) | sum theta (N) | sum zeta (N, response-time models) | sum nu (N or N*J, quantile models)]
+    int64_t nu_len() const { return cfg.model == ERM_MODEL_LATENTQR ? N : (cfg.model == ERM_MODEL_CROSSQR ? N * (int64_t)J : 0); }
+    int64_t summary_len() const override { return item_trace_width() + N + (is_rt() ? N : 0) + nu_len(); }
+    int summary_add(double* acc) override {
+        HIPCHK(hipSetDevice(cfg.device));
+        std::vector<double> m;
+        if (int rc = item_sums(m)) return rc;
+        DevBuf tmp;
+        if (int rc = tmp.alloc(m.size() * sizeof(double))) return rc;
+        HIPCHK(hipMemcpyAsync(tmp.p, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        auto add = [&](double* dst, const double* src, int64_t n) {
+            hipLaunchKernelGGL(acc_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, dst, src, (long long)n);
+        };
+        int64_t o = 0;
+        add(acc, tmp.as<double>(), (int64_t)m.size()); o += (int64_t)m.size();
+        add(acc + o, dSumTheta.as<double>(), N); o += N;
+        if (is_rt()) { add(acc + o, dSumZeta.as<double>(), N); o += N; }
+        if (nu_len() > 0) add(acc + o, dSumNu.as<double>(), nu_len());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));          // tmp dies here
+        return 0;
+    }
+    int summary_unpack(const double* mean, erm_state* out) const override {
+        unpack_items(mean, out);
+        int64_t o = item_trace_width();
+        if (out->theta) memcpy(out->theta, mean + o, N * sizeof(double));
+        o += N;
+        if (is_rt()) { if (out->zeta) memcpy(out->zeta, mean + o, N * sizeof(double)); o += N; }
+        if (out->nu && nu_len() > 0) {
+            if (cfg.model == ERM_MODEL_LATENTQR) memcpy(out->nu, mean + o, N * sizeof(double));
+            else for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) out->nu[(size_t)j * N + i] = mean[o + (size_t)i * J + j];     // device row-major -> column-major
         }
         return 0;
     }
@@ -1203,6 +1268,33 @@ template <typename real> struct Engine : EngineBase {
 }  // namespace
 
 struct erm_engine { std::unique_ptr<EngineBase> e; };
+
+// Chain farm (first bullet; north_star): nChain INDEPENDENT chains, chain l on device devices[l] with random stream
+// chain_id = l and its own copy of the data; one host thread per chain drives its engine's stream; no communication while sampling.
+// Post.mean (src/GibbsRtIrt.pl.jl:327-343: mean over iterations AND chains jointly) = (sum over chains of their post-burn-in sums) /
+// (total rows): the sums of the chains that share a device are added on that device, the devices' vectors are summed by ONE
+// ncclAllReduce over RCCL (xGMI), and device 0's copy is divided by the count.
+struct erm_farm {
+    erm_config cfg{};
+    std::vector<std::unique_ptr<erm_engine>> eng;      // eng[l]: chain l
+    std::vector<int> dev;                                // dev[l]: its device
+    std::vector<int> udev;                               // distinct devices, in order of first use
+    std::vector<ncclComm_t> comms;                       // one communicator rank per distinct device (empty until the first reduction over > 1 device)
+    bool used_rccl = false;
+    ~erm_farm() { for (auto c : comms) if (c) (void)g_rccl.CommDestroy(c); }
+    // runs f(l) for every chain on its own host thread; returns the first non-zero code (its message becomes this thread's last error)
+    template <typename Fn> int parallel(Fn&& f) {
+        const int n = (int)eng.size();
+        std::vector<int> rc(n, 0);
+        std::vector<std::string> msg(n);
+        std::vector<std::thread> th;
+        th.reserve(n);
+        for (int l = 0; l < n; ++l) th.emplace_back([&, l] { rc[l] = f(l); if (rc[l]) msg[l] = g_err; });
+        for (auto& t : th) t.join();
+        for (int l = 0; l < n; ++l) if (rc[l]) return fail(rc[l], "chain " + std::to_string(l) + ": " + msg[l]);
+        return 0;
+    }
+};
 
 extern "C" {
 
@@ -1266,6 +1358,126 @@ int erm_copy(void* dst, const void* src, size_t bytes)
     HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
     return 0;
 }
+
+/* ---- chain farm ---- */
+int erm_farm_create(const erm_config* cfg, const int32_t* devices, int32_t n_chains, erm_farm_handle* out)
+{
+    if (!cfg || !out || !devices) return fail(ERM_ERR_ARG, "cfg/devices/out is NULL");
+    *out = nullptr;
+    if (n_chains < 1 || n_chains > 255) return fail(ERM_ERR_ARG, "n_chains must be in [1, 255]");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    std::unique_ptr<erm_farm> f(new erm_farm());
+    f->cfg = *cfg;
+    for (int l = 0; l < n_chains; ++l) {
+        if (devices[l] < 0 || devices[l] >= ndev) return fail(ERM_ERR_ARG, "chain " + std::to_string(l) + ": no such device " + std::to_string(devices[l]));
+        erm_config c = *cfg;
+        c.device = devices[l]; c.chain_id = l; c.n_chain = 1;      // every chain records n_iter rows of its own
+        erm_handle h = nullptr;
+        if (int rc = erm_create(&c, &h)) return fail(rc, "chain " + std::to_string(l) + ": " + g_err);
+        f->eng.emplace_back(h);
+        f->dev.push_back(devices[l]);
+        bool seen = false;
+        for (int d : f->udev) seen = seen || d == devices[l];
+        if (!seen) f->udev.push_back(devices[l]);
+    }
+    *out = f.release();
+    return ERM_OK;
+}
+void erm_farm_destroy(erm_farm_handle f) { delete f; }
+#define CHK_F if (!f) return fail(ERM_ERR_ARG, "farm handle is NULL")
+int32_t erm_farm_chains(erm_farm_handle f) { return f ? (int32_t)f->eng.size() : -1; }
+erm_handle erm_farm_engine(erm_farm_handle f, int32_t chain) { return (f && chain >= 0 && chain < (int32_t)f->eng.size()) ? f->eng[chain].get() : nullptr; }
+int erm_farm_set_data(erm_farm_handle f, const uint8_t* Y, const double* logT, const double* X)
+{
+    CHK_F;
+    return f->parallel([&](int l) { return f->eng[l]->e->set_data(Y, logT, X); });
+}
+int erm_farm_set_state(erm_farm_handle f, int32_t chain, const erm_state* st)
+{
+    CHK_F;
+    if (chain < 0 || chain >= (int32_t)f->eng.size()) return fail(ERM_ERR_ARG, "no such chain");
+    return f->eng[chain]->e->set_state(st);
+}
+int erm_farm_get_state(erm_farm_handle f, int32_t chain, erm_state* st)
+{
+    CHK_F;
+    if (chain < 0 || chain >= (int32_t)f->eng.size()) return fail(ERM_ERR_ARG, "no such chain");
+    return f->eng[chain]->e->get_state(st);
+}
+int erm_farm_run(erm_farm_handle f, int64_t nsweeps)
+{
+    CHK_F;
+    return f->parallel([&](int l) { return f->eng[l]->e->run(nsweeps); });
+}
+int erm_farm_reset_trace(erm_farm_handle f)
+{
+    CHK_F;
+    for (auto& e : f->eng) if (int rc = e->e->reset_trace()) return rc;
+    return 0;
+}
+int64_t erm_farm_post_count(erm_farm_handle f)
+{
+    if (!f) return -1;
+    int64_t n = 0;
+    for (auto& e : f->eng) n += e->e->post_rows;
+    return n;
+}
+int erm_farm_used_rccl(erm_farm_handle f) { return f ? (f->used_rccl ? 1 : 0) : -1; }
+int erm_farm_get_trace(erm_farm_handle f, int which, double* out)
+{
+    CHK_F;
+    if (!out) return fail(ERM_ERR_ARG, "out is NULL");
+    // Julia layout [nIter][width][nChain], nIter fastest: chain l's (nIter x width x 1) block is contiguous at offset l * nIter * width
+    const int64_t wd = f->eng[0]->e->trace_width(which);
+    if (wd <= 0) return fail(ERM_ERR_ARG, "this model has no such trace");
+    const int64_t blk = (int64_t)f->cfg.n_iter * wd;
+    return f->parallel([&](int l) { return f->eng[l]->e->get_trace(which, out + (size_t)l * blk); });
+}
+int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
+{
+    CHK_F;
+    if (!out) return fail(ERM_ERR_ARG, "state is NULL");
+    const int64_t total = erm_farm_post_count(f);
+    if (total <= 0) return fail(ERM_ERR_STATE, "no post-burn-in sweeps recorded");
+    const int64_t len = f->eng[0]->e->summary_len();
+    const int nd = (int)f->udev.size();
+    // per-device accumulators: the chains of a device add their sums in chain order
+    std::vector<DevBuf> acc(nd);
+    for (int d = 0; d < nd; ++d) {
+        HIPCHK(hipSetDevice(f->udev[d]));
+        if (int rc = acc[d].alloc((size_t)len * sizeof(double))) return rc;      // zeroed
+    }
+    for (size_t l = 0; l < f->eng.size(); ++l) {
+        int d = 0;
+        while (f->udev[d] != f->dev[l]) ++d;
+        if (int rc = f->eng[l]->e->summary_add(acc[d].as<double>())) return fail(rc, "chain " + std::to_string(l) + ": " + g_err);
+    }
+    // one all-reduce over the devices (RCCL over xGMI).  ERM_FARM_FORCE_RCCL=1 takes this path with a one-device communicator too (tests)
+    const bool force = getenv("ERM_FARM_FORCE_RCCL") != nullptr;
+    if (nd > 1 || force) {
+        if (int rc = g_rccl.load()) return rc;
+        if (f->comms.empty()) {
+            f->comms.assign(nd, nullptr);
+            RCCLCHK(g_rccl.CommInitAll(f->comms.data(), nd, f->udev.data()));
+        }
+        RCCLCHK(g_rccl.GroupStart());
+        for (int d = 0; d < nd; ++d) {
+            HIPCHK(hipSetDevice(f->udev[d]));
+            RCCLCHK(g_rccl.AllReduce(acc[d].p, acc[d].p, (size_t)len, ncclDouble, ncclSum, f->comms[d], nullptr));
+        }
+        RCCLCHK(g_rccl.GroupEnd());
+        for (int d = 0; d < nd; ++d) { HIPCHK(hipSetDevice(f->udev[d])); HIPCHK(hipStreamSynchronize(nullptr)); }
+        f->used_rccl = true;
+    }
+    std::vector<double> m((size_t)len);
+    HIPCHK(hipSetDevice(f->udev[0]));
+    HIPCHK(hipMemcpy(m.data(), acc[0].p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost));
+    const double inv = 1.0 / (double)total;
+    for (auto& v : m) v *= inv;
+    return f->eng[0]->e->summary_unpack(m.data(), out);
+}
+
 const char* erm_last_error(void) { return g_err.c_str(); }
 const char* erm_version(void) { return "ertirt-amd 0.1.0 (gfx950)"; }
 

@@ -225,16 +225,55 @@ def simulateData(MCMC: _GibbsBase, truePara: InputPara, *, type="norm", seed=432
     return MCMC
 
 
-def sample_b(MCMC: _GibbsBase, *, intercept=False, itemtype="2pl", cov2one=None):
+def _sample_farm(MCMC: _GibbsBase, intercept, onepl, cov2one, devices):
+    """sample! with Cond.nChain INDEPENDENT chains, chain l on GPU devices[l mod len(devices)] (erm_farm_*, include/ertirt.h): the chains
+    run concurrently inside the library, Post.ra / rt / qr / logLike get chain l in slab l, and Post.mean is the joint mean over
+    iterations and chains (src/GibbsRtIrt.pl.jl:327-343) reduced over the devices by one RCCL all-reduce.  Chain 0 starts from
+    MCMC.Para (the constructor's setInitialValues); chain l > 0 from its own setInitialValues draw on random stream l."""
+    import copy
+    C = MCMC.Cond
+    if MCMC.shard is not None:
+        raise ValueError("a subject-sharded sampler cannot also farm chains")
+    if MCMC.Data is None:
+        raise ValueError("Data is required")
+    devs = [int(devices[l % len(devices)]) for l in range(C.nChain)]
+    farm = _lib.Farm(devs, model=MCMC._model, n_item=C.nItem, n_subj=C.nSubj, n_feat=C.nFeat, n_iter=C.nIter, n_chain=1, n_burnin=C.nBurnin,
+                     intercept=int(intercept), one_pl=int(onepl), cov2one=int(cov2one), q_rt=C.qRt, seed=MCMC.seed, precision=_PREC[MCMC.precision],
+                     trace_mode=_TRACE[MCMC.trace], **MCMC.engine_opts)
+    D = MCMC.Data
+    logT = None if MCMC._model == _lib.MODEL_MLIRT else np.asarray(D.logT, dtype=np.float64)
+    X = None
+    if MCMC._model not in (_lib.MODEL_CROSSQR, _lib.MODEL_CROSS, _lib.MODEL_NULL) and C.nFeat > 0:
+        X = np.asarray(D.X, dtype=np.float64)
+    farm.set_data(np.asarray(D.Y), logT, X)
+    for l in range(C.nChain):
+        if l == 0:
+            farm.set_state(0, **MCMC._state_for_engine())
+        else:
+            other = copy.copy(MCMC)
+            other.chain_id = l
+            other.setInitialValues()
+            farm.set_state(l, **other._state_for_engine())
+    farm.run(C.nIter)
+    MCMC._fill_post(farm)
+    MCMC._update_para(farm.engine(0))
+    MCMC.farm = farm
+    return MCMC
+
+
+def sample_b(MCMC: _GibbsBase, *, intercept=False, itemtype="2pl", cov2one=None, devices=None):
     """sample!(MCMC; intercept, itemtype, cov2one) -- src/GibbsRtIrt.pl.jl:210,278; Cross :265; Latent :271.
     Runs Cond.nIter * Cond.nChain sweeps (the reference's interleaved `for m in 1:nIter, l in 1:nChain` loop over ONE
-    shared Para), fills MCMC.Post, leaves the final state in MCMC.Para and returns MCMC."""
+    shared Para), fills MCMC.Post, leaves the final state in MCMC.Para and returns MCMC.
+    devices = [gpu ordinals]: the nChain chains become INDEPENDENT chains farmed over those GPUs instead (see _sample_farm)."""
     if itemtype not in ("1pl", "2pl"):
         raise ValueError("Invalid input: the item type must be '1pl' or '2pl'.")   # same text as :213,281
     if cov2one is None:
         cov2one = MCMC._cov2one_default
     if intercept and not MCMC._has_intercept:
         raise TypeError(f"sample! for {type(MCMC).__name__} has no `intercept` keyword")
+    if devices is not None:
+        return _sample_farm(MCMC, intercept, itemtype == "1pl", cov2one, list(devices))
     eng = MCMC._engine_for(intercept, itemtype == "1pl", cov2one)
     eng.reset_trace()
     eng.set_state(**MCMC._state_for_engine())

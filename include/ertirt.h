@@ -154,6 +154,33 @@ int erm_set_shard_rccl(erm_handle h, int rank, int count, int64_t n_subj_total, 
 /* hipMemcpy(dst, src, bytes, hipMemcpyDefault): lets a host-side exchange stage the buffers above without binding HIP itself. */
 int erm_copy(void* dst, const void* src, size_t bytes);
 
+/* Chain farm: the reference's nChain chains as INDEPENDENT chains, one per GPU (north_star).  Replaces the chain index of
+ * `for m in 1:nIter, l in 1:nChain` (src/GibbsRtIrt.pl.jl:289) and the joint mean over iterations and chains (:327-343).  Chain l runs on
+ * HIP device devices[l] (devices may repeat) with random stream chain_id = l and a full copy of the data; cfg->device, cfg->chain_id and
+ * cfg->n_chain are ignored (every chain records cfg->n_iter rows).  One host thread per chain inside the library drives that chain's
+ * stream, so the chains sample concurrently and never communicate.  erm_farm_get_mean is the only collective: the post-burn-in sums
+ * of the chains on one device are added on that device, the devices' vectors are summed by ONE ncclAllReduce (RCCL over xGMI, bound at
+ * run time as for erm_set_shard_rccl; skipped when all chains share one device unless ERM_FARM_FORCE_RCCL is set) and divided by the
+ * total number of post-burn-in rows.  Deliberate deviation from the reference: its nChain > 1 is ONE chain whose sweeps are dealt
+ * round-robin to nChain trace slabs (erm_create with n_chain > 1 reproduces that); independent chains leave Post.mean unchanged in
+ * expectation and make R-hat meaningful.
+ * erm_farm_get_trace fills Post.ra / rt / qr / logLike [nIter][width][nChain] with chain l in slab l.  erm_farm_engine lends chain l's
+ * engine (owned by the farm) for erm_get_item_trace / erm_get_diagnostics / erm_get_timing. */
+typedef struct erm_farm* erm_farm_handle;
+int erm_farm_create(const erm_config* cfg, const int32_t* devices, int32_t n_chains, erm_farm_handle* out);
+void erm_farm_destroy(erm_farm_handle f);
+int32_t erm_farm_chains(erm_farm_handle f);
+erm_handle erm_farm_engine(erm_farm_handle f, int32_t chain);
+int erm_farm_set_data(erm_farm_handle f, const uint8_t* Y, const double* logT, const double* X);   /* as erm_set_data, to every chain */
+int erm_farm_set_state(erm_farm_handle f, int32_t chain, const erm_state* st);                     /* each chain's own setInitialValues */
+int erm_farm_get_state(erm_farm_handle f, int32_t chain, erm_state* st);
+int erm_farm_run(erm_farm_handle f, int64_t nsweeps);                                              /* nsweeps sweeps of EVERY chain, concurrently */
+int erm_farm_reset_trace(erm_farm_handle f);
+int erm_farm_get_trace(erm_farm_handle f, int which, double* out);
+int erm_farm_get_mean(erm_farm_handle f, erm_state* out);
+int64_t erm_farm_post_count(erm_farm_handle f);
+int erm_farm_used_rccl(erm_farm_handle f);                  /* 1 if the last erm_farm_get_mean reduced over RCCL */
+
 const char* erm_last_error(void);
 const char* erm_version(void);
 
