@@ -1435,9 +1435,9 @@ __global__ void diag_kernel(const T* tr, long long ncol, long long ld, int nIter
 //   gen 0 MlIrt : X[:,1] ~ Bernoulli(1/2), X[:,2:] ~ N(0,1), theta ~ N(X beta, 1)
 //   gen 1 RtIrt : X ~ N(0,1), (theta, zeta) = X beta + N2(0, Sigp), logT ~ N(lambda_j - zeta_i, sig2t_j) truncated to (0, inf)
 //   gen 2 Null  : (theta, zeta) ~ N2(0, Sigp), logT as RtIrt
-//   gen 3 Cross : (theta, zeta) ~ N2(0, Sigp), logT = lambda_j - zeta_i - theta_i rho_j + 0.3 e
-//   gen 4 Latent: theta ~ N(0,1), X ~ N(0,1), zeta = [X theta] beta + 0.3 e, logT = lambda_j - zeta_i + N(0,1)
-//   e ("noise"): 0 N(0,1), 1 t_5, 2 Gamma(1/2, 1) - 1
+//   gen 3 Cross : (theta, zeta) ~ N2(0, Sigp), logT = lambda_j - zeta_i - theta_i rho_j + e
+//   gen 4 Latent: theta ~ N(0,1), X ~ N(0,1), zeta = [X theta] beta + e, logT = lambda_j - zeta_i + N(0,1)
+//   e ("noise"): 0 N(0, 0.3), 1 t_5, 2 Gamma(1/2, 1) - 1   (the 0.3 belongs to the normal type only: src/SimTools.jl:238-247)
 // Y_ij ~ Bernoulli(logistic(a_j (theta_i - b_j))) always.  logT is written raw; center_kernel subtracts the column means afterwards.
 // ---------------------------------------------------------------------------------------------------------------------
 struct GenArgs {
@@ -1445,9 +1445,9 @@ struct GenArgs {
     const double* truth;       // a[J] b[J] lambda[J] sig2t[J] rho[J] | Sigp chol L00 L10 L11 | beta (RtIrt: [F][2] row-major; MlIrt [F]; Latent [F+1])
     long long N; int J, F, gen, noise; uint64_t seed;
 };
-__device__ inline double gen_noise(Stream& s, int kind)
+__device__ inline double gen_noise(Stream& s, int kind)      // src/SimTools.jl:238-247, 322-328: Normal(0, 0.3) | TDist(5) | Gamma(1/2, 1) - 1
 {
-    if (kind == 0) return normal<double>(s);
+    if (kind == 0) return 0.3 * normal<double>(s);
     if (kind == 1) { const double zn = normal<double>(s); return zn / sqrt(chisq(s, 5.0) / 5.0); }
     const double u = uniform<double>(s);
     const double g = gamma_mt(s, 1.5) * u * u;                            // Gamma(a) = Gamma(a + 1) U^(1/a), a = 1/2 (Marsaglia-Tsang needs a >= 1)
@@ -1476,7 +1476,7 @@ __global__ void gen_kernel(GenArgs G)
     const double z0 = normal<double>(ss), z1 = normal<double>(ss);
     double th, ze;
     if (G.gen == 0) { th = mt + z0; ze = 0.0; }
-    else if (G.gen == 4) { th = z0; ze = mz + th * beta[F] + 0.3 * gen_noise(ss, G.noise); }
+    else if (G.gen == 4) { th = z0; ze = mz + th * beta[F] + gen_noise(ss, G.noise); }
     else { th = mt + L[0] * z0; ze = mz + L[1] * z0 + L[2] * z1; }
     G.theta[i] = th; G.zeta[i] = ze;
     for (int j = 0; j < J; ++j) {
@@ -1486,7 +1486,7 @@ __global__ void gen_kernel(GenArgs G)
         if (G.gen == 0) continue;
         double lt;
         if (G.gen == 1 || G.gen == 2) lt = truncnorm0(sc, lam[j] - ze, sqrt(sg[j]));
-        else if (G.gen == 3) lt = lam[j] - ze - th * rho[j] + 0.3 * gen_noise(sc, G.noise);
+        else if (G.gen == 3) lt = lam[j] - ze - th * rho[j] + gen_noise(sc, G.noise);
         else lt = lam[j] - ze + normal<double>(sc);
         C[(size_t)i * J + j] = (real)lt;
     }

@@ -147,17 +147,67 @@ function state_arrays(P::InputPara)
     (dense(P.θ), dense(P.a), dense(P.b), dense(P.ζ), dense(P.λ), dense(P.σ²t), dense(vec(P.β)), dense(vec(P.Σp)), dense(P.ρ), dense(vec(P.ν)))
 end
 
+# nChain INDEPENDENT chains, chain l on GPU devices[l] (erm_farm_*, include/ertirt.h): the library samples them concurrently (one host
+# thread per chain) and reduces Post.mean over the devices with one RCCL all-reduce.  Chain 1 starts from MCMC.Para, chain l > 1 from a
+# fresh setInitialValues draw, as nChain separately constructed samplers would.
+function sampleFarm!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool, devices)
+    C = M.Cond
+    M.shard === nothing || error("a subject-sharded sampler cannot also farm chains")
+    devs = Int32[devices[mod1(l, length(devices))] for l in 1:C.nChain]
+    cfg = ErmConfig(modelid(M), C.nItem, C.nSubj, C.nFeat, C.nIter, 1, C.nBurnin, intercept, onepl, cov2one, 0, 0, C.qRt,
+                    M.seed, 0, M.precision, 1, 0, 0, 0, 0, 0)
+    f = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:erm_farm_create, LIB[]), Cint, (Ref{ErmConfig}, Ptr{Int32}, Int32, Ref{Ptr{Cvoid}}), cfg, devs, C.nChain, f))
+    try
+        Y = Array{UInt8}(M.Data.Y)
+        logT = modelid(M) == MODEL_MLIRT ? Float64[] : dense(M.Data.logT)
+        X = (modelid(M) in (MODEL_CROSSQR, MODEL_CROSS, MODEL_NULL) || C.nFeat == 0) ? Float64[] : dense(M.Data.X)
+        GC.@preserve Y logT X check(ccall((:erm_farm_set_data, LIB[]), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}), f[], Y, ptr(logT), ptr(X)))
+        first = M.Para
+        for l in 1:C.nChain
+            l > 1 && setInitialValues(M)                     # a fresh draw for every further chain
+            arrs = state_arrays(M.Para)
+            GC.@preserve arrs check(ccall((:erm_farm_set_state, LIB[]), Cint, (Ptr{Cvoid}, Int32, Ref{ErmState}), f[], l - 1, ErmState(map(ptr, arrs)...)))
+        end
+        M.Para = first
+        check(ccall((:erm_farm_run, LIB[]), Cint, (Ptr{Cvoid}, Int64), f[], C.nIter))
+        h0 = ccall((:erm_farm_engine, LIB[]), Ptr{Cvoid}, (Ptr{Cvoid}, Int32), f[], 0)
+        trace(which) = begin
+            w = ccall((:erm_trace_width, LIB[]), Int64, (Ptr{Cvoid}, Cint), h0, which)
+            out = Array{Float64}(undef, C.nIter, w, C.nChain)
+            check(ccall((:erm_farm_get_trace, LIB[]), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), f[], which, out)); out
+        end
+        Post = M.Post
+        Post.ra = trace(TRACE_RA)
+        Post.logLike = trace(TRACE_LOGLIKE)
+        modelid(M) != MODEL_MLIRT && (Post.rt = trace(TRACE_RT))
+        Post.qr = trace(TRACE_QR)
+        N, J, F = C.nSubj, C.nItem, C.nFeat
+        nb = modelid(M) == MODEL_MLIRT ? F + 1 : modelid(M) in (MODEL_RTIRT, MODEL_NULL) ? 2 * (F + 1) : modelid(M) in (MODEL_LATENTQR, MODEL_LATENT) ? F + 2 : 0
+        nnu = modelid(M) == MODEL_LATENTQR ? N : modelid(M) == MODEL_CROSSQR ? N * J : 0
+        bufs = (zeros(N), zeros(J), zeros(J), zeros(N), zeros(J), zeros(J), zeros(nb), zeros(4), zeros(J), zeros(nnu))
+        GC.@preserve bufs check(ccall((:erm_farm_get_mean, LIB[]), Cint, (Ptr{Cvoid}, Ref{ErmState}), f[], ErmState(map(ptr, bufs)...)))
+        Post.mean = InputPara(θ = bufs[1], a = bufs[2], b = bufs[3], ζ = bufs[4], λ = bufs[5], σ²t = bufs[6], β = bufs[7], Σp = bufs[8], ρ = bufs[9], ν = bufs[10])
+    finally
+        ccall((:erm_farm_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), f[])
+    end
+    return M
+end
+
 """
-    sample!(MCMC; intercept=false, itemtype="2pl", cov2one)
+    sample!(MCMC; intercept=false, itemtype="2pl", cov2one, devices=nothing)
 
 Same contract as the reference's `sample!`: runs `Cond.nIter * Cond.nChain` sweeps of the interleaved loop, fills
 `MCMC.Post.{ra,rt,qr,logLike,mean}`, leaves the final state in `MCMC.Para`, returns `MCMC`.
+`devices = 0:7` runs the `Cond.nChain` chains as independent chains, one per listed GPU (cycled), instead: `Post` has the same shapes,
+chain `l` in slab `l`; `Post.mean` is the joint mean over iterations and chains.
 """
 function sample!(M::GibbsAMD; intercept = false, itemtype::Union{String} = "2pl",
-                 cov2one = !(M isa GibbsRtIrtLatentQr || M isa GibbsRtIrtLatent))
+                 cov2one = !(M isa GibbsRtIrtLatentQr || M isa GibbsRtIrtLatent), devices = nothing)
     if !(itemtype in ["1pl", "2pl"])
         error("Invalid input: the item type must be '1pl' or '2pl'.")
     end
+    devices === nothing || return sampleFarm!(M, Bool(intercept), itemtype == "1pl", Bool(cov2one), collect(devices))
     C = M.Cond
     h = engine!(M, intercept, itemtype == "1pl", cov2one)
     check(ccall((:erm_reset_trace, LIB[]), Cint, (Ptr{Cvoid},), h))

@@ -900,3 +900,69 @@ void orc_step(const orc_config* c, const orc_data* d, orc_state* s, int step, ui
     case 17: draw_sigp_latent(c, d, s, t); break;
     }
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Synthetic data: the five generators of /root/reference/src/SimTools.jl restated with the DEVICE's stream addressing
+ * (csrc/erm_kernels.hpp gen_kernel), so that erm_simulate_data can be compared value by value.
+ *   subject stream (DATA_SUBJ = 12, i, 0, sweep 0), consumed in this order: the nFeat covariates X[i, f] ~ N(0,1)
+ *   (setDataMlIrt: X[i, 1] ~ Bernoulli(1/2) instead -- its uniform is drawn AFTER that column's unused normal), then z0, z1 ~ N(0,1),
+ *   then (Latent only) the zeta noise;  cell stream (DATA_CELL = 13, i, j, sweep 0): the uniform of Y[i, j], then the logT variate(s).
+ *   gen 0  setDataMlIrt        src/SimTools.jl:349-368   theta = X beta + z0 (trueStd = 1)
+ *   gen 1  setDataRtIrt        src/SimTools.jl:149-178   (theta, zeta) = X beta + L (z0, z1), L = chol(Sigp); logT ~ N(lambda_j - zeta_i, sig2t_j) truncated to (0, inf)
+ *   gen 2  setDataRtIrtNull    src/SimTools.jl:117-144   (theta, zeta) = L (z0, z1); logT as gen 1
+ *   gen 3  setDataRtIrtCross   src/SimTools.jl:220-255   (theta, zeta) = L (z0, z1); logT = lambda_j - zeta_i - theta_i rho_j + e,
+ *                                                        e ~ N(0, 0.3) ("norm") | t_5 ("tail") | Gamma(1/2, 1) - 1 ("skew")
+ *   gen 4  setDataRtIrtLatent  src/SimTools.jl:304-343   theta = z0; zeta = [X theta] beta + e (same three types); logT = lambda_j - zeta_i + N(0,1)
+ * Y[i, j] ~ Bernoulli(logistic(a_j (theta_i - b_j))) for every generator (BernoulliLogit).  Like the host generators this is the
+ * reference's DISTRIBUTION; Julia's Random.seed! stream cannot be reproduced.
+ * beta: gen 0 [nFeat]; gen 1 [nFeat][2] column-major (theta column, then zeta column); gen 4 [nFeat + 1].
+ * Outputs column-major: X [N x nFeat], Y [N x J] bytes, logT [N x J]; theta, zeta [N].
+ * --------------------------------------------------------------------------------------------------------------------- */
+enum { ORC_SITE_DATA_SUBJ = 12, ORC_SITE_DATA_CELL = 13 };
+
+static double gen_noise(orc_stream* s, int kind)        /* src/SimTools.jl:238-247, 322-328 */
+{
+    if (kind == 0) return 0.3 * orc_normal(s);                                             /* Normal(0, 0.3) */
+    if (kind == 1) { double zn = orc_normal(s); return zn / sqrt(orc_chisq(s, 5.0) / 5.0); }   /* TDist(5) */
+    double u = orc_unif(s);                                                                /* Gamma(1/2, 1) - 1: Gamma(a) = Gamma(a + 1) U^(1/a) */
+    return orc_gamma(s, 1.5) * u * u - 1.0;
+}
+
+void orc_simulate_data(int gen, int noise, uint64_t seed, int64_t N, int J, int F,
+                       const double* a, const double* b, const double* lambda, const double* sig2t, const double* rho,
+                       const double* Sigp /* vec, may be NULL = I */, const double* beta,
+                       double* X, double* theta, double* zeta, uint8_t* Y, double* logT)
+{
+    double L0 = 1.0, L1 = 0.0, L2 = 1.0;
+    if (Sigp) { L0 = sqrt(Sigp[0]); L1 = Sigp[1] / L0; L2 = sqrt(Sigp[3] - L1 * L1); }
+    ORC_OMP_FOR
+    for (int64_t i = 0; i < N; ++i) {
+        orc_stream ss = orc_stream_make(seed, 0, ORC_SITE_DATA_SUBJ, (uint32_t)i, 0u, 0u);
+        double mt = 0.0, mz = 0.0;
+        for (int f = 0; f < F; ++f) {
+            double x = orc_normal(&ss);
+            if (gen == 0 && f == 0) x = orc_unif(&ss) < 0.5 ? 1.0 : 0.0;
+            X[(size_t)f * N + i] = x;
+            if (gen == 0) mt += x * beta[f];
+            else if (gen == 1) { mt += x * beta[f]; mz += x * beta[F + f]; }
+            else if (gen == 4) mz += x * beta[f];
+        }
+        double z0 = orc_normal(&ss), z1 = orc_normal(&ss), th, ze;
+        if (gen == 0) { th = mt + z0; ze = 0.0; }
+        else if (gen == 4) { th = z0; ze = mz + th * beta[F] + gen_noise(&ss, noise); }
+        else { th = mt + L0 * z0; ze = mz + L1 * z0 + L2 * z1; }
+        theta[i] = th; zeta[i] = ze;
+        for (int j = 0; j < J; ++j) {
+            orc_stream sc = orc_stream_make(seed, 0, ORC_SITE_DATA_CELL, (uint32_t)i, (uint32_t)j, 0u);
+            double eta = a[j] * (th - b[j]);
+            Y[(size_t)j * N + i] = orc_unif(&sc) < 1.0 / (1.0 + exp(-eta)) ? 1 : 0;
+            if (gen == 0) continue;
+            double lt;
+            if (gen == 1 || gen == 2) lt = orc_truncnorm0(&sc, lambda[j] - ze, sqrt(sig2t[j]));
+            else if (gen == 3) lt = lambda[j] - ze - th * rho[j] + gen_noise(&sc, noise);
+            else lt = lambda[j] - ze + orc_normal(&sc);
+            logT[(size_t)j * N + i] = lt;
+        }
+    }
+}

@@ -53,6 +53,8 @@ def oracle():
         lib.orc_moments.restype = None
         lib.orc_step.argtypes = [C.POINTER(orc_config), C.POINTER(orc_data), C.POINTER(orc_state), C.c_int, C.c_uint32]
         lib.orc_step.restype = None
+        lib.orc_simulate_data.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 12
+        lib.orc_simulate_data.restype = None
         lib.orc_set_threads.argtypes = [C.c_int]
         lib.orc_set_threads.restype = None
         _orc = lib
@@ -66,6 +68,22 @@ def orc_sample(which, n, par0=None, par1=None, *, seed=1234, site=15, sweep=1):
     oracle().orc_sample_batch(which, seed, site, sweep, n, None if p0 is None else p0.ctypes.data,
                               None if p1 is None else p1.ctypes.data, out.ctypes.data)
     return out
+
+
+def orc_simulate(gen, N, J, F, *, a, b, lam=None, sig2t=None, rho=None, Sigp=None, beta=None, seed=4321, noise=0):
+    """The oracle's restatement of setData* (gen 0 MlIrt, 1 RtIrt, 2 Null, 3 Cross, 4 Latent) with the device's stream addressing.
+    Returns dict(X, theta, zeta, Y, logT), column-major."""
+    def p(v):
+        return None if v is None else np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1, order="F"))
+    a_, b_, l_, s_, r_, S_, B_ = p(a), p(b), p(lam), p(sig2t), p(rho), p(Sigp), p(beta)
+    X = np.zeros((N, max(F, 1)), order="F")
+    th, ze = np.zeros(N), np.zeros(N)
+    Y = np.zeros((N, J), dtype=np.uint8, order="F")
+    logT = np.zeros((N, J), order="F")
+    ptr = lambda v: None if v is None else v.ctypes.data
+    oracle().orc_simulate_data(gen, noise, seed, N, J, F, ptr(a_), ptr(b_), ptr(l_), ptr(s_), ptr(r_), ptr(S_), ptr(B_),
+                               X.ctypes.data, th.ctypes.data, ze.ctypes.data, Y.ctypes.data, logT.ctypes.data)
+    return dict(X=X[:, :F], theta=th, zeta=ze, Y=Y, logT=logT)
 
 
 class OracleProblem:

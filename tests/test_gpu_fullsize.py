@@ -103,7 +103,8 @@ def test_configs4_reproducible_continuable_geometry_invariant_and_recovers_truth
     assert np.array_equal(ma["theta"], me["theta"]) and np.array_equal(ma["zeta"], me["zeta"])
     del eng, b
     # another launch geometry changes only the summation order of the statistics
-    g = pu.run_device("rtirt", Y, logT, X, init, 8, precision=precision, qRt=0.5, trace_full=False, lanes_per_row=16, block_threads=512, grid_blocks=300)
+    geo = dict(lanes_per_row=16, block_threads=512, grid_blocks=300) if precision == "f32" else dict(lanes_per_row=16, block_threads=256, grid_blocks=1500)
+    g = pu.run_device("rtirt", Y, logT, X, init, 8, precision=precision, qRt=0.5, trace_full=False, **geo)
     tol = 2e-4 if precision == "f32" else 1e-9
     assert np.max(np.abs(a["item"][:8] - g["item"]) / np.maximum(np.abs(a["item"][:8]), 1.0)) < tol
     # recovery of the generating values (README.md:61-77 style).  After 60 sweeps from a = 1, b = 0 the common scale of (a, theta) is

@@ -61,12 +61,45 @@ def test_generators_follow_the_reference_distributions(name, truth, gen):
 @pytest.mark.parametrize("type_,check", [("tail", lambda e: 1.2 < e.std() < 1.4 and np.mean(np.abs(e) > 3) > 0.015),   # t5: sd sqrt(5/3), heavy tails
                                          ("skew", lambda e: abs(e.mean() + 0.5) < 0.02 and abs(e.std() - np.sqrt(0.5)) < 0.03 and e.min() >= -1)])
 def test_noise_types_of_the_cross_generator(type_, check):
+    """rand(TDist(5)) / rand(Gamma(0.5, 1)) .- 1 enter logT UNSCALED (src/SimTools.jl:240-245); only the normal type has sd 0.3."""
     C = _cond(N=6000, J=8, F=0)
     tp = pkg.setTrueParaRtIrtCross(C, seed=2)
     M = pkg.GibbsRtIrtCross(C, precision="f64")
     pkg.simulateData(M, tp, type=type_, seed=9)
-    e = (np.asarray(M.Data.logT) - (tp.lam[None, :] - tp.zeta[:, None] - tp.theta[:, None] * tp.rho[None, :])) / 0.3
+    e = np.asarray(M.Data.logT) - (tp.lam[None, :] - tp.zeta[:, None] - tp.theta[:, None] * tp.rho[None, :])
     assert check(e.ravel())
+
+
+GENS = [("GibbsMlIrt", "setTrueParaMlIrt", 0), ("GibbsRtIrt", "setTrueParaRtIrt", 1), ("GibbsRtIrtNull", "setTrueParaRtIrt", 2),
+        ("GibbsRtIrtCross", "setTrueParaRtIrtCross", 3), ("GibbsRtIrtLatent", "setTrueParaRtIrtLatent", 4)]
+
+
+@pytest.mark.parametrize("name,truth,gen", GENS)
+@pytest.mark.parametrize("type_", ["norm", "tail", "skew"])
+def test_device_generators_equal_the_oracle_restatement_value_by_value(name, truth, gen, type_):
+    """erm_simulate_data against oracle/erm_oracle.c::orc_simulate_data (setData* of src/SimTools.jl:117-368 restated with the same
+    (DATA_SUBJ, i) / (DATA_CELL, i, j) stream addressing): X, theta, zeta, logT to 1e-12, Y bit for bit (fp64 engine)."""
+    if type_ != "norm" and gen not in (3, 4):
+        pytest.skip("only setDataRtIrtCross / setDataRtIrtLatent take a noise type")
+    C = _cond(N=3000, J=9, F=3)
+    N, J, F = C.nSubj, C.nItem, C.nFeat
+    tp = getattr(pkg, truth)(C, seed=11)
+    if gen == 1:
+        tp.Sigp = np.array([[1.3, 0.4], [0.4, 0.8]])               # a full covariance exercises the Cholesky factor
+    M = getattr(pkg, name)(C, precision="f64")
+    pkg.simulateData(M, tp, type=type_, seed=2024)
+    Fk = 0 if gen in (2, 3) else F
+    o = pu.orc_simulate(gen, N, J, Fk, a=tp.a, b=tp.b, lam=tp.lam if gen else None, sig2t=(tp.sig2t if np.size(tp.sig2t) else np.ones(J)) if gen else None,
+                        rho=tp.rho if gen == 3 else None, Sigp=np.asarray(tp.Sigp).reshape(-1, order="F") if np.size(tp.Sigp) else None,
+                        beta=np.asarray(tp.beta).reshape(-1, order="F") if Fk else None, seed=2024, noise={"norm": 0, "tail": 1, "skew": 2}[type_])
+    assert np.array_equal(np.asarray(M.Data.Y, dtype=np.uint8), o["Y"])
+    assert np.max(np.abs(tp.theta - o["theta"])) < 1e-12
+    if gen:
+        assert np.max(np.abs(tp.zeta - o["zeta"])) < 1e-12
+        assert np.max(np.abs(np.asarray(M.Data.logT) - o["logT"])) < 1e-12
+    if Fk:
+        assert np.max(np.abs(np.asarray(M.Data.X) - o["X"])) < 1e-12
+
 
 
 def test_installed_data_set_equals_set_data_on_the_same_values():
