@@ -95,9 +95,9 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename real> __device__ __forceinline__ real row_normal(uint32_t wa, uint32_t wb)
+template <typename real> __device__ __forceinline__ real row_normal(uint32_t wa, uint32_t wb, [[maybe_unused]] const double2* tab = nullptr)
 {
-    if constexpr (sizeof(real) == 8) return fm::sqrt(-2.0 * fm::log(word_to_unif<double>(wa))) * cospi(2.0 * word_to_unif<double>(wb));
+    if constexpr (sizeof(real) == 8) return fm::sqrt(-2.0 * (tab ? fm::log(word_to_unif<double>(wa), tab) : fm::log(word_to_unif<double>(wa)))) * cospi(2.0 * word_to_unif<double>(wb));
     else return r_sqrt(real(-2) * r_log(word_to_unif<real>(wa))) * r_cos2pi(word_to_unif<real>(wb));
 }
 
@@ -677,6 +677,13 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 #endif
     };
     stamp(0);
+    // fp64 engine: the 2 KB table of fm::log (filled here; the first barrier below -- the head's, or the staging barrier -- publishes it)
+    [[maybe_unused]] const double2* logtab = nullptr;
+    if constexpr (sizeof(real) == 8) {
+        __shared__ double2 sh_logtab[128];
+        fm::fill_log_table(sh_logtab, (int)threadIdx.x, (int)blockDim.x);
+        logtab = sh_logtab;
+    }
     const uint8_t* __restrict__ gY = A.Y;
     const real* __restrict__ gC = A.C;
     const real* __restrict__ gX = A.X;
@@ -899,7 +906,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                 const real mu0 = (MODEL == MLIRT || MODEL == RTIRT) ? mu0a : real(0);
                 const real parV = r_rcp(r_rcp(sig11) + sA);
                 const real parM = parV * (r_div(mu0, sig11) + sB);
-                th = parM + r_sqrt(parV) * row_normal<real>(rw0, rw1);
+                th = parM + r_sqrt(parV) * row_normal<real>(rw0, rw1, logtab);
             }
             if (fam_rt(MODEL) || fam_lq(MODEL)) {
                 // zeta: src/Draw.pl.jl:132-141 / :161-174 (LatentQr) / :147-156 (Latent) / :119-127 (Null: prior N(0,1), Sigp unused)
@@ -912,13 +919,13 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                 }
                 const real parV = r_rcp(r_rcp(s0) + sum_isig);
                 const real parM = parV * (r_div(mu0, s0) + sC);
-                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
+                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3, logtab);
             }
             if (fam_cq(MODEL) && PHASE == 1) {
                 // zeta: src/Draw.pl.jl:192-206 (CrossQr) / :179-187 (Cross) (zero prior mean, prior variance Sigp[2,2]); sA = sum of weights here
                 const real parV = r_rcp(r_rcp(sig22) + sA);
                 const real parM = parV * sC;
-                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3);
+                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3, logtab);
             }
             if (rok) {
                 if (PHASE == 0) {
@@ -1021,14 +1028,16 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                 const bool on = lane < n;
                 const uint2 e = pq[T * QCAP + ((qhd[T] + (on ? lane : 0)) & (QCAP - 1))];
                 const int cc = (int)(e.x & 0x7FFFFFFFu);
-                int r2, j2;
-                locate(cc, r2, j2);
-                const double zz = 0.5 * fabs((double)sh_a[j2] * ((double)sh_th[r2] - (double)sh_b[j2]));
                 double x;
-                if (T == 0) x = pg1_value_tail(zz, e.y);
-                else if (T == 1) x = pg1_value_central(e.y);
-                else if (T == 2) x = pg1_value_mid(e.y);
-                else x = pg1_value_large(zz >= 1.5625 ? zz : 2.0, e.y, (e.x >> 31) != 0u);
+                if (T == 1) x = pg1_value_central(e.y);             // small-z left pieces do not depend on z at all
+                else if (T == 2) x = pg1_value_mid(e.y, logtab);
+                else {
+                    int r2, j2;
+                    locate(cc, r2, j2);
+                    const double zz = 0.5 * fabs((double)sh_a[j2] * ((double)sh_th[r2] - (double)sh_b[j2]));
+                    if (T == 0) x = pg1_value_tail(zz, e.y, logtab);
+                    else x = pg1_value_large(zz >= 1.5625 ? zz : 2.0, e.y, (e.x >> 31) != 0u);
+                }
                 if (on) om[cc] = (real)(0.25 * x);
                 qhd[T] += n; qn[T] -= n;
             };
@@ -1047,7 +1056,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                     bool acc_ = d.accept;
                     if (__any(d.unsure)) {                           // inside a guard band: the reference form decides, and its value is stored at once
                         double o2;
-                        const bool a2 = pg1_attempt_ref<double>((double)z, w0, w1, w2, w3, o2);
+                        const bool a2 = pg1_attempt_ref_call((double)z, w0, w1, w2, w3, &o2);
                         if (d.unsure) { acc_ = a2; if (a2) om[c] = (real)o2; }
                     }
                     const bool give_up = att + 1u >= (uint32_t)MAX_TRIES;
@@ -1247,7 +1256,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
             }
 #pragma unroll
             for (int q = 0; q < NSTAT; ++q) S[q] += (double)bs[q];
-            if constexpr (sizeof(real) == 8 && PHASE == 0) { if (A.mode == 1) bl -= fm::log(bprod); }
+            if constexpr (sizeof(real) == 8 && PHASE == 0) { if (A.mode == 1) bl -= fm::log(bprod, logtab); }
             llc += (double)bl;
         }
         if (jv) {
@@ -1541,11 +1550,15 @@ template <typename real>
 __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uint32_t sweep, long long n,
                                     const double* par0, const double* par1, double* out)
 {
+    __shared__ double2 sh_logtab[128];
+    fm::fill_log_table(sh_logtab, (int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     Stream st(seed, 0u, site, (uint32_t)k, 0u, sweep);
     double v = 0.0;
     switch (which) {
+    case 15: v = fm::log(par0[k], sh_logtab); break;           // the table form of the cell path's logarithm
     case 0: v = (double)uniform<real>(st); break;
     case 1: v = (double)normal<real>(st); break;
     case 2: v = (double)expo<real>(st); break;

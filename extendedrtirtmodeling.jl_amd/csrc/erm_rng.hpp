@@ -86,6 +86,26 @@ __device__ __forceinline__ double log(double x)
     const double lm = fma(s2, P * z, s2);
     return fma((double)e, 0.693147180559945309417, lm);
 }
+// log(x) with a 128-entry table in LDS (fill_log_table): x = m 2^e, m in [1, 2), k = the top 7 fraction bits of m, c_k = 1 + (k + 1/2)/128,
+// tab[k] = (1/c_k, log c_k); r = m/c_k - 1 (one fma, |r| <= 2^-8) and log x = e ln2 + log c_k + log1p(r), log1p by 6 terms (next: r^7/7 < 2e-18).
+// 17 instructions with a 7-deep dependent chain, against 33 with a 25-deep one for the table-free form; absolute error ~2e-16 (the relative
+// error near x = 1 is larger: every caller adds the result to, or takes the root of, something of order one)
+__device__ __forceinline__ void fill_log_table(double2* tab, int tid, int nthreads)
+{
+    for (int k = tid; k < 128; k += nthreads) { const double c = 1.0 + ((double)k + 0.5) * (1.0 / 128.0); tab[k] = make_double2(1.0 / c, ::log(c)); }
+}
+__device__ __forceinline__ double log(double x, const double2* tab)
+{
+    const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
+    const int e = (int)((hi >> 20) & 0x7FFu) - 1023;
+    const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), (int)lo);
+    const double2 t = tab[(hi >> 13) & 0x7Fu];
+    const double r = fma(m, t.x, -1.0);
+    double P = fma(r, -1.0 / 6.0, 0.2);
+    P = fma(P, r, -0.25); P = fma(P, r, 1.0 / 3.0); P = fma(P, r, -0.5);
+    const double l1p = fma(P * r, r, r);
+    return fma((double)e, 0.693147180559945309417, t.y) + l1p;
+}
 // e^{-a}, 0 <= a (-> 0 beyond 700): a = k ln2 + r, |r| <= ln2/2, Taylor series of e^{-r} to r^13/13! (4e-18), scaled by 2^-k
 __device__ __forceinline__ double exp_neg(double a)
 {
@@ -399,6 +419,17 @@ __device__ __forceinline__ bool pg1_attempt(float z, uint32_t w0, uint32_t w1, u
 // by draw against the oracle, and against pg1_attempt_ref on 2^24 draws).
 //   the series needs no second term: rho_2 = 5 e^{6 e1} <= 3.6e-8 for every x an attempt can propose (e^{2 e1} <= 1.93e-3), less than
 //   the band on V <= S_1, so V > S_1 + band implies V > S_2 (reject) and V <= S_1 - band implies accept.
+// The reference form as a REAL call: the row pass reaches it for about 4 attempts in 10^5, and inlined into the attempt loop its OCML
+// exponentials and logarithms set that loop's register pressure (29 of its 33 VGPR spills).  Behind a call the callee's registers are
+// its own, and the caller saves its live values only on the rare path that calls.
+__device__ __attribute__((noinline)) bool pg1_attempt_ref_call(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double* out)
+{
+    double o;
+    const bool a = pg1_attempt_ref<double>(z, w0, w1, w2, w3, o);
+    *out = o;
+    return a;
+}
+
 enum PgPiece : int { PG_NONE = 0, PG_TAIL = 1, PG_CENTRAL = 2, PG_MID = 3, PG_LARGE = 4 };   // which fp64 evaluation an accepted draw needs
 
 struct PgDecision {
@@ -482,6 +513,11 @@ __device__ __forceinline__ double pg1_value_tail(double z, uint32_t w1)         
     const double PId = 3.14159265358979323846;
     return 0.64 - fm::div(fm::log(word_to_unif<double>(w1)), fma(0.5 * z, z, 0.125 * PId * PId));
 }
+__device__ __forceinline__ double pg1_value_tail(double z, uint32_t w1, const double2* tab)      // the same with the LDS log table
+{
+    const double PId = 3.14159265358979323846;
+    return 0.64 - fm::div(fm::log(word_to_unif<double>(w1), tab), fma(0.5 * z, z, 0.125 * PId * PId));
+}
 __device__ __forceinline__ double pg1_value_central(uint32_t w1)                 // X = 1 / Z^2, Z = Phi^-1(pa) = qc n / d
 {
     const double qc = word_to_unif<double>(w1) * 0.10564977366685525 - 0.5;
@@ -490,9 +526,10 @@ __device__ __forceinline__ double pg1_value_central(uint32_t w1)                
     const double ratio = fm::div(d, qc * n);
     return ratio * ratio;
 }
-__device__ __forceinline__ double pg1_value_mid(uint32_t w1)                     // X = 1 / Z^2, |Z| = n / d
+__device__ __forceinline__ double pg1_value_mid(uint32_t w1, const double2* tab = nullptr)       // X = 1 / Z^2, |Z| = n / d
 {
-    const double r = fm::sqrt(-fm::log(word_to_unif<double>(w1) * 0.10564977366685525));
+    const double pa = word_to_unif<double>(w1) * 0.10564977366685525;
+    const double r = fm::sqrt(-(tab ? fm::log(pa, tab) : fm::log(pa)));
     double n, d;
     as241::mid(r, n, d);
     if (__any(r > 5.0)) { double n2, d2; as241::far(r, n2, d2); n = r > 5.0 ? n2 : n; d = r > 5.0 ? d2 : d; }

@@ -72,6 +72,8 @@ def test_fp64_cell_path_elementary_functions():
     d = _dev(11, x.size, x)
     assert np.max(np.abs(d - np.log(x)) / np.maximum(np.abs(np.log(x)), 1e-8)) < 4e-16 * 8
     assert _dev(11, 1, np.array([1.0]))[0] == 0.0
+    t = _dev(15, x.size, x)                                     # the LDS-table form: absolute accuracy (its callers add to / take roots of O(1) values)
+    assert np.max(np.abs(t - np.log(x)) / np.maximum(np.abs(np.log(x)), 1.0)) < 5e-16
     a = np.concatenate([g.uniform(0, 40, N), g.uniform(0, 1e-3, 1000), g.uniform(600, 800, 1000), [0.0]])
     d = _dev(12, a.size, a)
     ref = np.exp(-np.minimum(a, 700.0))

@@ -2,9 +2,13 @@
 """Turns gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/<tag>_*.csv, profiles/<tag>_summary.md and profiles/traffic.json."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
+prec = sys.argv[2] if len(sys.argv) > 2 else "f64"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+src, dst = os.path.join(root, "gpurun_out", f"{tag}_{prec}"), os.path.join(root, "profiles")
+tag = f"{tag}_{prec}"
+BYTES = {"f32": 13.0, "f64": 25.0}[prec]            # GibbsRtIrt algorithmic bytes per cell-update (SURVEY.md 8(d))
+CELL = {"f32": 4.0, "f64": 8.0}[prec]
 os.makedirs(dst, exist_ok=True)
 
 
@@ -38,7 +42,7 @@ write = json.load(open(os.path.join(dst, f"{tag}_write_counters.json")))["WRITE_
 cal = json.load(open(os.path.join(dst, f"{tag}_fetch_cal_counters.json")))["FETCH_SIZE"]
 wl = bench["config"]["workload"]
 N = int(wl.split("nSubj=")[1].split()[0]); J = int(wl.split("nItem=")[1].split()[0])
-known = N * J * 9.0 / 1024.0                       # KB read by the row-sum phase alone: omega 4 + Y 1 + logT 4 bytes per cell
+known = N * J * (2.0 * CELL + 1.0) / 1024.0        # KB read by the row-sum phase alone: omega + Y (1 byte) + logT per cell
 corr = known / cal                                 # gfx950: FETCH_SIZE under-reports coalesced streaming reads (MI355X_MICROARCH.md, HBM)
 traffic = (fetch * corr + write) * 1024.0
 key = f"rtirt:{N}x{J}:{bench['dtype']}"
@@ -57,13 +61,13 @@ tj[key] = {"valu": valu, "traffic_bytes_per_launch": traffic, "fetch_size_kb_raw
            "calibration": f"row-sum phase alone (ERM_PASS_STOP=5) reads {known:.0f} KB and reports FETCH_SIZE {cal:.0f} KB", "source": f"profiles/{tag}_*"}
 json.dump(tj, open(tj_path, "w"), indent=1)
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary ({tag})\n\ncommand: `python3 bench.py --cpu-sweeps 0` (the default workload and step counts; counter passes: `--steps 200 --warmup 20 --no-profile`)\n\n")
+    f.write(f"# rocprofv3 summary ({tag})\n\ncommand: `python3 bench.py --precision {prec} --no-fp32 --cpu-sweeps 0` (the default workload and step counts; counter passes: `--steps 200 --warmup 20 --no-profile`)\n\n")
     f.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for r in rows[:4]:
         f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |\n")
     f.write(f"\nbench line of the same run: ms_per_step {bench['ms_per_step']:.4f}, roofline {json.dumps(bench.get('roofline'))}\n\n")
     f.write(f"pass_kernel HBM-side traffic per launch: FETCH_SIZE {fetch:.0f} KB x {corr:.2f} (calibrated) + WRITE_SIZE {write:.0f} KB = {traffic/1e6:.1f} MB "
-            f"(algorithmic {13*N*J/1e6:.1f} MB)\n")
+            f"(algorithmic {BYTES*N*J/1e6:.1f} MB)\n")
     if valu:
         f.write(f"\nVALU: {valu['valu_insts_per_launch']:.3g} wave-instructions per launch = {valu['valu_insts_per_cell_update']:.0f} per cell-update; VALU busy "
                 f"{100*valu['valu_busy_frac']:.0f} % of the kernel's cycles (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32))\n")
