@@ -278,6 +278,7 @@ __device__ __forceinline__ void far(double r, double& n, double& d)          // 
     n = fma(n, r, 5.46378491116411436990e+0); d = fma(d, r, 5.99832206555887937690e-1);
     n = fma(n, r, 6.65790464350110377720e+0); d = fma(d, r, 1.0);
 }
+__device__ __attribute__((noinline)) void far_fix(double r, double& n, double& d) { double n2, d2; far(r, n2, d2); if (r > 5.0) { n = n2; d = d2; } }
 __device__ __forceinline__ double central(double r) { double n, d; central(r, n, d); return n / d; }
 __device__ __forceinline__ double mid(double r) { double n, d; mid(r, n, d); return n / d; }
 __device__ __forceinline__ double far(double r) { double n, d; far(r, n, d); return n / d; }
@@ -532,13 +533,13 @@ __device__ __forceinline__ double pg1_value_mid(uint32_t w1, const double2* tab 
     const double r = fm::sqrt(-(tab ? fm::log(pa, tab) : fm::log(pa)));
     double n, d;
     as241::mid(r, n, d);
-    if (__any(r > 5.0)) { double n2, d2; as241::far(r, n2, d2); n = r > 5.0 ? n2 : n; d = r > 5.0 ? d2 : d; }
+    if (__any(r > 5.0)) as241::far_fix(r, n, d);            // quantile arguments below e^-25: a real call
     const double ratio = fm::div(d, n);
     return ratio * ratio;
 }
 // z >= 1/t: IG(mu = 1/z, 1) from Z = Phi^-1(u1) (Michael-Schucany-Haas): with w = mu Z^2, x1 = 4 mu / (sqrt(4 + w) + sqrt(w))^2, the
 // second root is mu^2 / x1 (the same roots as the reference form's 2 sqrt(w) / (sqrt(w) sqrt(4 + w) + w), divided through by sqrt(w))
-__device__ __forceinline__ double pg1_value_large(double z, uint32_t w1, bool second)
+__device__ __attribute__((noinline)) double pg1_value_large(double z, uint32_t w1, bool second)      // a real call: z >= 1/t left pieces are rare
 {
     const double Z = ndtri(word_to_unif<double>(w1));
     const double mu = fm::rcp(z), w = mu * Z * Z;
