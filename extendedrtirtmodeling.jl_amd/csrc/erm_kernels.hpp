@@ -81,7 +81,8 @@ template <typename real> struct PassArgs {
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // -DERM_DIAG_BUILD only: skip everything after stage k (0 = run everything); ignored by the shipped library
     unsigned long long* dbg_ts;   // diagnostics only (ERM_TIMELINE): [2 workgroups][16 waves][16 checkpoints] of the 100 MHz wall clock
-    int pgq_off;          // fp64 engine: byte offset in dynamic LDS of the PG phase's value queues ([nWaves][4][128] x 8 bytes)
+    int acc_off;          // byte offset in dynamic LDS of the per-wave item accumulators [nWaves][NSTAT][J], the LAST region of a launch's LDS; the
+                          // fp64 engine's PG-phase value queues ([nWaves][4][128] x 8 bytes) are overlaid on it
     uint32_t row_base;    // subject index of local row 0 in the whole data set (subject-sharded chains; 0 otherwise): the random streams are
                           // addressed by the GLOBAL subject index, so a chain does not depend on how its subjects are spread over devices
 };
@@ -656,8 +657,10 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* sh_struct = reinterpret_cast<double*>(smem);        // 8 + 2*PMAX doubles
-    double* sh_acc = sh_struct + 8 + 2 * PMAX;                  // [nWaves][NSTAT][J]
-    double* sh_gacc = sh_acc + (size_t)nWaves * NSTAT * J;      // [nWaves][NG]
+    // the per-wave item accumulators close the launch's dynamic LDS (A.acc_off): they are first written in the column phase, so the fp64
+    // engine's PG-phase value queues (dead by then) share that space and only their excess over it is extra LDS
+    double* sh_acc = reinterpret_cast<double*>(smem + A.acc_off);    // [nWaves][NSTAT][J]
+    double* sh_gacc = sh_struct + 8 + 2 * PMAX;                 // [nWaves][NG]
     real* sh_item = reinterpret_cast<real*>(sh_gacc + (size_t)nWaves * NG);    // [NITEMARR][J]
     real* sh_a = sh_item, *sh_b = sh_item + J, *sh_a2 = sh_item + 2 * J, *sh_a2b = sh_item + 3 * J;
     real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
@@ -1021,7 +1024,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
             // queue holds 64 entries the whole wave evaluates that ONE piece for 64 cells, every lane busy, and stores the omegas.
             // Positions come from ballots (wave-synchronous: no atomics); the value depends only on (cell, word 1), never on the lane.
             constexpr int QCAP = 128;                                // a queue holds < 64 entries before a push of <= 64
-            uint2* pq = reinterpret_cast<uint2*>(smem + A.pgq_off) + (size_t)wave * 4 * QCAP;
+            uint2* pq = reinterpret_cast<uint2*>(smem + A.acc_off) + (size_t)wave * 4 * QCAP;
             int qhd[4] = {0, 0, 0, 0}, qn[4] = {0, 0, 0, 0};         // wave-uniform: first entry and number of entries per piece
             auto flush = [&](int T, int n) {                         // evaluate and store the first n (<= 64) entries of queue T
                 wave_sync();

@@ -219,13 +219,19 @@ template <typename real> struct Engine : EngineBase {
         const int q = p() + 1;
         return q * (q + 1) / 2 + q + 1;
     }
+    // dynamic LDS of a row pass = fixed part | (fused: tiny-step scratch) | tail, where the tail holds the per-wave item accumulators
+    // [nWaves][NSTAT][J] and -- overlaid on them, the two are never live together -- the fp64 engine's PG-phase value queues
+    // (4 pieces x 128 entries x 8 bytes per wave)
+    size_t tail_lds(int phase, int nWaves) const {
+        const size_t acc = (size_t)nWaves * nstat(phase) * J * sizeof(double);
+        const size_t q = (sizeof(real) == 8 && phase == 0) ? (size_t)nWaves * 4 * 128 * 8 : 0;
+        return std::max(acc, q);
+    }
     size_t pass_lds(int phase, int nWaves) const {
         const int ng = stat_sizes(phase) - nstat(phase) * J;
-        size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * ((size_t)nstat(phase) * J + (size_t)ng);
-        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave + (size_t)rows_per_block * (Fk + 4)) * sizeof(real) + pgq_bytes(nWaves);
+        size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * (size_t)ng;
+        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave + (size_t)rows_per_block * (Fk + 4)) * sizeof(real) + 8 + tail_lds(phase, nWaves);
     }
-    // fp64 engine: the PG phase's per-wave value queues (4 pieces x 128 entries x 8 bytes), at the very end of the dynamic LDS of a launch
-    static size_t pgq_bytes(int nWaves) { return sizeof(real) == 8 ? (size_t)nWaves * 4 * 128 * 8 + 8 : 0; }
 
     int init() override {
         N = cfg.n_subj; J = cfg.n_item; F = cfg.n_feat;
@@ -281,6 +287,7 @@ template <typename real> struct Engine : EngineBase {
         if (grid_blocks < 1) grid_blocks = 1;
         // each workgroup owns a contiguous range of subjects, split evenly over its waves
         // (the per-subject LDS caches grow with the rows a workgroup owns: very long data sets get more workgroups than CUs)
+        bool rounded = false;
         for (;;) {
             rows_per_block = (N + grid_blocks - 1) / grid_blocks;
             grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
@@ -289,8 +296,17 @@ template <typename real> struct Engine : EngineBase {
             if (fused() && nWaves > 1) rows_per_wave = (int)((rows_per_block + nWaves - 2) / (nWaves - 1)) + 1;
             for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
             const size_t need_lds = std::max(std::max(lds_pass[0], lds_pass[1]), fused() ? fused_lds() : (size_t)0);
-            if (need_lds <= 158 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
-            grid_blocks *= 2;
+            if (need_lds <= 158 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) {
+                // more workgroups than the chip holds at once run in rounds: fill the last round (a partial one costs as much as a full one)
+                const int slots = cu_count * per_cu;
+                if (cfg.grid_blocks == 0 && grid_blocks > slots && grid_blocks % slots != 0 && !rounded) {
+                    rounded = true;
+                    grid_blocks = (grid_blocks + slots - 1) / slots * slots;
+                    continue;
+                }
+                break;
+            }
+            grid_blocks += std::max(1, grid_blocks / 4);          // every extra round of workgroups costs a head and a tail: grow gently
         }
         if (getenv("ERM_NO_FUSE")) fuse_ok = false;                       // diagnostics: the two-kernel schedule (stand-alone tiny kernel)
         if (!fuse_ok || (fused() && fused_lds() > 160 * 1024)) {       // the tiny step's scratch does not fit next to the pass layout (or ERM_NO_FUSE): keep the two-kernel schedule
@@ -430,9 +446,9 @@ template <typename real> struct Engine : EngineBase {
         a.dbg_stop = diag_stop("ERM_PASS_STOP");
         a.dbg_ts = dDbgTs.as<unsigned long long>();
         a.row_base = (uint32_t)row_base;
-        {   // the queues close the launch's dynamic LDS (8-byte aligned)
+        {   // the accumulator / queue tail closes the launch's dynamic LDS (every part before it is a multiple of 8 bytes)
             const size_t total = fz ? fused_lds() : lds_pass[phase];
-            a.pgq_off = (int)((total - pgq_bytes(block_threads / 64) + 7) & ~(size_t)7);
+            a.acc_off = (int)((total - tail_lds(phase, block_threads / 64)) & ~(size_t)7);
         }
         return a;
     }
