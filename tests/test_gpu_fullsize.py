@@ -117,3 +117,25 @@ def test_configs4_reproducible_continuable_geometry_invariant_and_recovers_truth
     assert np.std(ma["lambda_"] - tp.lam) < 0.03 and abs(np.mean(ma["lambda_"] - tp.lam)) < 0.15 and np.corrcoef(ma["lambda_"], tp.lam)[0, 1] > 0.995
     assert np.max(np.abs(ma["sig2t"] / tp.sig2t - 1)) < 0.12 and np.corrcoef(ma["sig2t"], tp.sig2t)[0, 1] > 0.99
     assert np.corrcoef(ma["theta"], tp.theta)[0, 1] > 0.95 and np.corrcoef(ma["zeta"], tp.zeta)[0, 1] > 0.99
+
+
+def test_fullsize_f32_chain_within_three_mc_standard_errors_of_the_oracle_chain(rtirt):
+    """The fp32 fast mode against the oracle's fp64 chain AT A BASELINE SIZE (configs[2], 100 000 x 50), same addressed variates: posterior
+    means of every item-level parameter within 3 Monte-Carlo standard errors, the standard errors from the ORACLE chain (sd of its post-burn-in
+    draws / sqrt(ESS)) -- SURVEY.md 8(c)(4).  The oracle runs its OpenMP mode (bit-identical to one thread): 80 sweeps in a few seconds."""
+    Y, logT, X, init, _ = rtirt
+    T = 80
+    dev = pu.run_device("rtirt", Y, logT, X, init, T, precision="f32", qRt=0.5, trace_full=False)
+    pu.oracle().orc_set_threads(16)
+    try:
+        tr = pu.OracleProblem("rtirt", Y, logT, X, init, qRt=0.5).run(T)
+    finally:
+        pu.oracle().orc_set_threads(1)
+    ess_rhat = pu.ge.load_package().gibbs.ess_rhat
+    orc_item = np.column_stack([tr["ra"][:, N:], tr["rt"][:, N:]])          # a, b | lambda, sig2t
+    dev_item = dev["item"][:, :4 * J]
+    post = orc_item[T // 2:]
+    se = np.array([post[:, k].std(ddof=1) / np.sqrt(min(max(ess_rhat(post[:, k])[0], 1.0), post.shape[0])) for k in range(post.shape[1])])
+    z = np.abs(dev_item[T // 2:].mean(0) - post.mean(0)) / se
+    assert z.max() < 3.0, z.max()
+    assert np.max(np.abs(dev["ll"][:, 0, 0] - tr["ll"]) / np.abs(tr["ll"])) < 1e-4
