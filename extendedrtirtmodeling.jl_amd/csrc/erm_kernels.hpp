@@ -1386,6 +1386,27 @@ __global__ void __launch_bounds__(256) shard_pack_kernel(const double* gslab, in
     reduce_rows(gslab, nb, NS, out, (int)threadIdx.x, (int)blockDim.x);
 }
 
+// Post.ra / rt / qr in Julia layout: the device keeps a subject-level trace as [row = m * nChain + l][subject] (coalesced stores, one row per
+// sweep); Julia's array is [nIter][width][nChain] with the iteration fastest.  dst[i * nIter + m] = (double) src[(m * nChain + l) * ld + i] for ONE
+// chain l, 32 x 32 tiles through LDS so that both the reads (along subjects) and the writes (along iterations) are coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256) trace_transpose_kernel(const T* src, long long ld, long long ncol, int nIter, int nChain, int l, double* dst)
+{
+    __shared__ double tile[32][33];
+    const long long i0 = (long long)blockIdx.x * 32;
+    const int m0 = (int)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r; const long long i = i0 + tx;
+        if (m < nIter && i < ncol) tile[r][tx] = (double)src[((long long)m * nChain + l) * ld + i];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long long i = i0 + r; const int m = m0 + tx;
+        if (i < ncol && m < nIter) dst[i * nIter + m] = tile[tx][r];
+    }
+}
+
 // dst[i] += src[i] (chain farms: post-burn-in sums of the chains that share a device, before the RCCL all-reduce over the devices)
 __global__ void __launch_bounds__(256) acc_kernel(double* dst, const double* src, long long n)
 {

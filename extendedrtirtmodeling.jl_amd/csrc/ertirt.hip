@@ -1093,8 +1093,26 @@ template <typename real> struct Engine : EngineBase {
         std::vector<double> it;
         if (int rc = fetch_item_trace(it)) return rc;
         const int64_t wi = item_trace_width();
-        std::vector<real> rowbuf(N);
+        // subject block of a trace: transposed to Julia's iteration-fastest layout ON the device (one chain at a time into a scratch buffer of
+        // nSubj x nIter doubles), then ONE contiguous copy per chain; if the scratch buffer cannot be had, row by row through the host
         auto subj = [&](const DevBuf& d, int64_t k0) -> int {
+            double* tmp = nullptr;
+            const size_t need = (size_t)N * (size_t)nIter * sizeof(double);
+            if (hipMalloc(reinterpret_cast<void**>(&tmp), need) == hipSuccess) {
+                int rc = 0;
+                for (int64_t l = 0; l < nChain && !rc; ++l) {
+                    hipLaunchKernelGGL((trace_transpose_kernel<real>), dim3((unsigned)((N + 31) / 32), (unsigned)((nIter + 31) / 32)), dim3(256), 0, stream,
+                                       d.as<real>(), (long long)N, (long long)N, (int)nIter, (int)nChain, (int)l, tmp);
+                    hipError_t e = hipGetLastError();
+                    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                    if (e == hipSuccess) e = hipMemcpy(out + nIter * (k0 + wd * l), tmp, need, hipMemcpyDeviceToHost);
+                    if (e != hipSuccess) rc = fail(ERM_ERR_HIP, std::string("trace transpose: ") + hipGetErrorString(e));
+                }
+                (void)hipFree(tmp);
+                return rc;
+            }
+            (void)hipGetLastError();
+            std::vector<real> rowbuf(N);
             for (int64_t r = 0; r < rows_cap; ++r) {
                 HIPCHK(hipMemcpy(rowbuf.data(), d.as<real>() + (size_t)r * N, N * sizeof(real), hipMemcpyDeviceToHost));
                 for (int64_t i = 0; i < N; ++i) at(r, k0 + i) = (double)rowbuf[i];
