@@ -1386,6 +1386,58 @@ __global__ void __launch_bounds__(256) shard_pack_kernel(const double* gslab, in
     reduce_rows(gslab, nb, NS, out, (int)threadIdx.x, (int)blockDim.x);
 }
 
+// erm_set_data on the device.  The caller's arrays are column-major (Julia): uploaded as they are, then
+//   colstats_cm_kernel : one workgroup per column j: K0_j = sum_i (Y_ij - 1/2), sum_i logT_ij (fp64, fixed order), validity flags
+//                        (bit 0: a Y that is not 0/1, bit 1: a non-finite logT);
+//   to_rows_kernel     : 32 x 32 tiles through LDS, dst[i][j] = (T)(src[j][i] - shift[j]) -- Y bytes, logT centred by its column mean
+//                        (subtracted in fp64 BEFORE the value is rounded to the engine's cell type), X;
+//   colsq_kernel       : per-workgroup partial sums over rows of the squared centred values ([block][J]).
+__global__ void __launch_bounds__(256) colstats_cm_kernel(const uint8_t* Y, const double* L, long long N, int has_l, double* out, int J, unsigned int* flags)
+{
+    const int j = blockIdx.x, tid = threadIdx.x;
+    double sk = 0.0, sl = 0.0;
+    unsigned int bad = 0u;
+    for (long long i = tid; i < N; i += 256) {
+        const uint8_t y = Y[(size_t)j * N + i];
+        bad |= (y > 1) ? 1u : 0u;
+        sk += (double)y - 0.5;
+        if (has_l) { const double v = L[(size_t)j * N + i]; bad |= (fabs(v) < 1.79e308) ? 0u : 2u; sl += v; }
+    }
+    __shared__ double shk[256], shl[256];
+    shk[tid] = sk; shl[tid] = sl;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) { shk[tid] += shk[tid + w]; shl[tid] += shl[tid + w]; } __syncthreads(); }
+    if (tid == 0) { out[j] = shk[0]; out[J + j] = shl[0]; }
+    if (bad) atomicOr(flags, bad);
+}
+template <typename S, typename T>
+__global__ void __launch_bounds__(256) to_rows_kernel(const S* src, long long N, int J, const double* shift, T* dst)
+{
+    __shared__ double tile[32][33];
+    const long long i0 = (long long)blockIdx.x * 32;
+    const int j0 = (int)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r; const long long i = i0 + tx;
+        if (j < J && i < N) tile[r][tx] = (double)src[(size_t)j * N + i] - (shift ? shift[j] : 0.0);
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long long i = i0 + r; const int j = j0 + tx;
+        if (i < N && j < J) dst[(size_t)i * J + j] = (T)tile[tx][r];
+    }
+}
+template <typename real>
+__global__ void __launch_bounds__(128) colsq_kernel(const real* C, long long N, int J, double* part)
+{
+    const long long per = (N + gridDim.x - 1) / gridDim.x, r0 = (long long)blockIdx.x * per, r1 = (r0 + per < N) ? r0 + per : N;
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        double sq = 0.0;
+        for (long long i = r0; i < r1; ++i) { const double c = (double)C[(size_t)i * J + j]; sq += c * c; }
+        part[(size_t)blockIdx.x * J + j] = sq;
+    }
+}
+
 // Post.ra / rt / qr in Julia layout: the device keeps a subject-level trace as [row = m * nChain + l][subject] (coalesced stores, one row per
 // sweep); Julia's array is [nIter][width][nChain] with the iteration fastest.  dst[i * nIter + m] = (double) src[(m * nChain + l) * ld + i] for ONE
 // chain l, 32 x 32 tiles through LDS so that both the reads (along subjects) and the writes (along iterations) are coalesced.

@@ -755,76 +755,82 @@ template <typename real> struct Engine : EngineBase {
     }
 
     // -------------------------------------------------------------------------------------------- data
+    // InputData (src/Base.pl.jl:67-78) -> the resident data set.  The column-major host arrays are uploaded as they are and turned into the
+    // engine's row-major buffers ON the device (transposition, column sums, centring of logT by its column means, centred sums of squares);
+    // the host only adds up per-workgroup partial sums in a fixed order and forms x'x (N p^2 flops).
     int set_data(const uint8_t* Y, const double* logT, const double* X) override {
         if (!Y) return fail(ERM_ERR_ARG, "Y is NULL");
         if (is_rt() && !logT) return fail(ERM_ERR_ARG, "logT is required for response-time models");
         if (Fk > 0 && !X) return fail(ERM_ERR_ARG, "X is required when n_feat > 0");
         HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamSynchronize(stream));
         const size_t NJ = (size_t)N * J;
         const double Ntot = sharded() ? (double)n_total : (double)N;      // a shard's column sums are completed over the devices
         const int pp = p();
         std::vector<double> cst(cst_size(J), 0.0);
         std::vector<double> g1((size_t)2 * J + PMAX * PMAX, 0.0);         // K0 | column sums of logT | x'x : summed over the devices
-        {   // Y -> row-major bytes; K0_j = sum_i kappa_ij  (kappa = Y - 0.5, src/Base.pl.jl:74)
-            std::vector<uint8_t> yr(NJ);
-            for (int j = 0; j < J; ++j) {
-                double k0 = 0.0;
-                const uint8_t* col = Y + (size_t)j * N;
-                for (int64_t i = 0; i < N; ++i) {
-                    if (col[i] > 1) return fail(ERM_ERR_ARG, "Y must be 0/1");
-                    yr[(size_t)i * J + j] = col[i];
-                    k0 += (double)col[i] - 0.5;
-                }
-                g1[j] = k0;
-            }
-            HIPCHK(hipMemcpy(dY.p, yr.data(), NJ, hipMemcpyHostToDevice));
+        DevBuf dYc, dLc, dStat, dFlag;
+        if (int rc = dYc.alloc(NJ)) return rc;
+        HIPCHK(hipMemcpy(dYc.p, Y, NJ, hipMemcpyHostToDevice));
+        if (is_rt()) { if (int rc = dLc.alloc(NJ * sizeof(double))) return rc; HIPCHK(hipMemcpy(dLc.p, logT, NJ * sizeof(double), hipMemcpyHostToDevice)); }
+        if (int rc = dStat.alloc((size_t)2 * J * sizeof(double))) return rc;
+        if (int rc = dFlag.alloc(sizeof(unsigned int))) return rc;
+        hipLaunchKernelGGL(colstats_cm_kernel, dim3(J), dim3(256), 0, stream, dYc.as<uint8_t>(), dLc.as<double>(), (long long)N, is_rt() ? 1 : 0, dStat.as<double>(), J, dFlag.as<unsigned int>());
+        const dim3 tgrid((unsigned)((N + 31) / 32), (unsigned)((J + 31) / 32));
+        hipLaunchKernelGGL((to_rows_kernel<uint8_t, uint8_t>), tgrid, dim3(256), 0, stream, dYc.as<uint8_t>(), (long long)N, J, (const double*)nullptr, dY.as<uint8_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        {
+            unsigned int flags = 0;
+            HIPCHK(hipMemcpy(&flags, dFlag.p, sizeof(flags), hipMemcpyDeviceToHost));
+            if (flags & 1u) return fail(ERM_ERR_ARG, "Y must be 0/1");
+            if (flags & 2u) return fail(ERM_ERR_ARG, "logT must be finite");
+            HIPCHK(hipMemcpy(g1.data(), dStat.p, (size_t)2 * J * sizeof(double), hipMemcpyDeviceToHost));      // K0 | column sums of logT
         }
-        if (is_rt()) {
-            for (int j = 0; j < J; ++j) {
-                const double* col = logT + (size_t)j * N;
-                double sm = 0.0;
-                for (int64_t i = 0; i < N; ++i) { if (!std::isfinite(col[i])) return fail(ERM_ERR_ARG, "logT must be finite"); sm += col[i]; }
-                g1[(size_t)J + j] = sm;
-            }
-        }
-        for (int u = 0; u < pp; ++u) for (int v = 0; v < pp; ++v) {     // x'x with x = [1 X]
+        for (int u = 0; u < pp; ++u) for (int v = u; v < pp; ++v) {     // x'x with x = [1 X]
             double t = 0.0;
-            for (int64_t i = 0; i < N; ++i) {
-                const double xu = u == 0 ? 1.0 : X[(size_t)(u - 1) * N + i], xv = v == 0 ? 1.0 : X[(size_t)(v - 1) * N + i];
-                t += xu * xv;
-            }
-            g1[(size_t)2 * J + u + v * PMAX] = t;
+            if (u == 0 && v == 0) t = (double)N;
+            else if (u == 0) { const double* xv = X + (size_t)(v - 1) * N; for (int64_t i = 0; i < N; ++i) t += xv[i]; }
+            else { const double* xu = X + (size_t)(u - 1) * N; const double* xv = X + (size_t)(v - 1) * N; for (int64_t i = 0; i < N; ++i) t += xu[i] * xv[i]; }
+            g1[(size_t)2 * J + u + v * PMAX] = t; g1[(size_t)2 * J + v + u * PMAX] = t;
         }
         if (int rc = shard_allsum(g1)) return rc;
         for (int j = 0; j < J; ++j) cst[cst_off_k0(J) + j] = g1[j];
         if (is_rt()) {
             // column-centred logT; mean/std(Data.logT) are the kwargs of drawItemIntensity (src/Draw.pl.jl:215)
-            std::vector<real> cr(NJ);
-            std::vector<double> g2(J, 0.0);
+            std::vector<double> mean(J), g2(J, 0.0);
             double tot = 0.0;
-            for (int j = 0; j < J; ++j) {
-                const double* col = logT + (size_t)j * N;
-                tot += g1[(size_t)J + j];
-                const double m = g1[(size_t)J + j] / Ntot;
-                double sq = 0.0;
-                for (int64_t i = 0; i < N; ++i) { const double c = col[i] - m; sq += c * c; cr[(size_t)i * J + j] = (real)c; }
-                cst[cst_off_m(J) + j] = m; g2[j] = sq;
-            }
+            for (int j = 0; j < J; ++j) { tot += g1[(size_t)J + j]; mean[j] = g1[(size_t)J + j] / Ntot; cst[cst_off_m(J) + j] = mean[j]; }
+            DevBuf dMean, dPart;
+            const int NB = 256;
+            if (int rc = dMean.alloc((size_t)J * sizeof(double))) return rc;
+            if (int rc = dPart.alloc((size_t)NB * J * sizeof(double))) return rc;
+            HIPCHK(hipMemcpy(dMean.p, mean.data(), (size_t)J * sizeof(double), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL((to_rows_kernel<double, real>), tgrid, dim3(256), 0, stream, dLc.as<double>(), (long long)N, J, dMean.as<double>(), dC.as<real>());
+            hipLaunchKernelGGL((colsq_kernel<real>), dim3(NB), dim3(128), 0, stream, dC.as<real>(), (long long)N, J, dPart.as<double>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(stream));
+            std::vector<double> part((size_t)NB * J);
+            HIPCHK(hipMemcpy(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int j = 0; j < J; ++j) { double sq = 0.0; for (int b = 0; b < NB; ++b) sq += part[(size_t)b * J + j]; g2[j] = sq; }
             if (int rc = shard_allsum(g2)) return rc;
             for (int j = 0; j < J; ++j) cst[cst_off_csq(J) + j] = g2[j];
             const double mu = tot / (Ntot * (double)J);
             double ss = 0.0;
             for (int j = 0; j < J; ++j) { const double dm = cst[cst_off_m(J) + j] - mu; ss += cst[cst_off_csq(J) + j] + Ntot * dm * dm; }
             cst[cst_off_mu(J)] = mu; cst[cst_off_mu(J) + 1] = std::sqrt(ss / (Ntot * (double)J - 1.0));
-            HIPCHK(hipMemcpy(dC.p, cr.data(), NJ * sizeof(real), hipMemcpyHostToDevice));
         }
         {   // X -> row-major
             for (int u = 0; u < pp; ++u) for (int v = 0; v < pp; ++v) cst[cst_off_xtx(J) + u + v * PMAX] = g1[(size_t)2 * J + u + v * PMAX];
             if (int rc = invert_xtx(cst)) return rc;
             if (Fk > 0) {
-                std::vector<real> xr((size_t)N * Fk);
-                for (int f = 0; f < Fk; ++f) for (int64_t i = 0; i < N; ++i) xr[(size_t)i * Fk + f] = (real)X[(size_t)f * N + i];
-                HIPCHK(hipMemcpy(dX.p, xr.data(), (size_t)N * Fk * sizeof(real), hipMemcpyHostToDevice));
+                DevBuf dXc;
+                if (int rc = dXc.alloc((size_t)N * Fk * sizeof(double))) return rc;
+                HIPCHK(hipMemcpy(dXc.p, X, (size_t)N * Fk * sizeof(double), hipMemcpyHostToDevice));
+                hipLaunchKernelGGL((to_rows_kernel<double, real>), dim3((unsigned)((N + 31) / 32), (unsigned)((Fk + 31) / 32)), dim3(256), 0, stream, dXc.as<double>(), (long long)N, Fk,
+                                   (const double*)nullptr, dX.as<real>());
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(stream));
             }
         }
         HIPCHK(hipMemcpy(dCst.p, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
