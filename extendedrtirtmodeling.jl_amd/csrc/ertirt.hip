@@ -270,7 +270,6 @@ template <typename real> struct Engine : EngineBase {
         const int max_threads = sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_THREADS;
         block_threads = cfg.block_threads > 0 ? cfg.block_threads : max_threads;
         if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= " + std::to_string(ERM_F32_THREADS) + " (fp32) / " + std::to_string(ERM_F64_THREADS) + " (fp64)");
-        const int R = 64 / W;
         // the per-wave item accumulators (nWaves x NSTAT x nItem doubles) dominate LDS for long tests: fewer waves per workgroup then
         if (cfg.block_threads == 0) {
             while (block_threads > 64) {
