@@ -184,10 +184,10 @@ def offline_counters(model, N, J, precision):
     return e
 
 
-def measure(pkg, ge_mod, torch, dist, args, model, N, J, F, precision, data, st, rank, world, local_rank, rehearse, shard, trace):
+def measure(pkg, ge_mod, torch, dist, args, model, N, J, F, precision, data, st, rank, world, local_rank, rehearse, shard, trace, truth=None):
     """warm-up + timed region of one engine on resident inputs; returns (dt seconds [max over ranks], timing dict, engine, n_loc)."""
     L = pkg._lib
-    Y, logT, X = data
+    Y, logT, X = data if data is not None else (None, None, True)
     rows = args.warmup + args.steps
     lo, n_loc = (0, N)
     if shard:       # every rank builds the same data set and keeps its rows
@@ -206,7 +206,10 @@ def measure(pkg, ge_mod, torch, dist, args, model, N, J, F, precision, data, st,
         box = [L.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         eng.set_shard_rccl(rank, world, N, lo, box[0])
-    eng.set_data(Y, logT, X)       # inputs resident in HBM from here on
+    if truth is not None:          # the data set is generated ON the device (erm_simulate_data: setDataRtIrt's distributions, data seed 1234)
+        eng.simulate_data(seed=1234, **truth)
+    else:
+        eng.set_data(Y, logT, X)   # inputs resident in HBM from here on
     eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in st.items()})
 
     def barrier():
@@ -347,11 +350,16 @@ def main():
         N4, J4 = (20000, 100) if rehearse else (500000, 100)
         a4 = argparse.Namespace(**vars(args))
         a4.steps, a4.warmup = min(args.steps, 100), min(args.warmup, 10)
-        data4 = make_data(pkg, model, N4, J4, F, seed=1234)
+        # 5e7 cells: generated on the device from setTrueParaRtIrt's item / structural truth (host generation would take half a minute per rank)
+        import numpy as np
+        tp4 = pkg.setTrueParaRtIrt(pkg.setCond(nSubj=N4, nItem=J4, nFeat=F, nIter=10, nChain=1), seed=np.random.default_rng(1234))
+        truth4 = dict(a=tp4.a, b=tp4.b, lambda_=tp4.lam, sig2t=tp4.sig2t, sigp=np.asarray(tp4.Sigp, dtype=np.float64).reshape(-1, order="F"),
+                      beta=np.asarray(tp4.beta, dtype=np.float64).reshape(-1, order="F"))
         st4 = init_state(model, N4, J4, F, rank)
-        dt4, tm4, eng4, _ = measure(model=model, N=N4, J=J4, F=F, precision=prec, data=data4, st=st4, trace="summary", **dict(common, args=a4))
+        dt4, tm4, eng4, _ = measure(model=model, N=N4, J=J4, F=F, precision=prec, data=None, st=st4, trace="summary", truth=truth4, **dict(common, args=a4))
         del eng4
         cfg4 = {"workload": f"GibbsRtIrt nSubj={N4} nItem={J4} nFeat={F}, one chain per GPU (BASELINE.json configs[4] per-GPU load), summary traces",
+                "data": "synthetic, generated on the device (erm_simulate_data)",
                 "value": float(N4) * J4 * a4.steps * world / dt4, "unit": "cell-updates/s", "ms_per_step": dt4 / a4.steps * 1e3, "steps": a4.steps, "warmup": a4.warmup,
                 "dtype": prec, "roofline": roofline(model, N4, J4, N4, prec, tm4)}
 
