@@ -417,7 +417,7 @@ __device__ __forceinline__ bool pg1_attempt(float z, uint32_t w0, uint32_t w1, u
 // pg1_attempt_ref<double>.  Only an ACCEPTED draw is then evaluated in fp64, and only its value (pg1_value_*): one log and one division
 // (tail), one AS 241 rational (left) -- instead of three fp64 exponentials, a log and a quantile per attempt.  Decisions, and therefore
 // which Philox block a cell's draw comes from, are those of the reference form; the value differs from it by rounding only (tests: draw
-// by draw against the oracle, and against pg1_attempt_ref on 2^24 draws).
+// by draw against the oracle, and against pg1_attempt_ref on 2^26 draws).
 //   the series needs no second term: rho_2 = 5 e^{6 e1} <= 3.6e-8 for every x an attempt can propose (e^{2 e1} <= 1.93e-3), less than
 //   the band on V <= S_1, so V > S_1 + band implies V > S_2 (reject) and V <= S_1 - band implies accept.
 // The reference form as a REAL call: the row pass reaches it for about 4 attempts in 10^5, and inlined into the attempt loop its OCML

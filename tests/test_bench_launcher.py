@@ -51,10 +51,12 @@ def test_two_ranks_with_the_hip_engine_and_a_collective_on_one_gpu():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ERM_BENCH_LAUNCH_ONLY"):
         e.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--nsubj", "4000", "--nitem", "12",
-                        "--clock-warmup-ms", "0", "--no-configs4"], env=e, capture_output=True, text=True, timeout=900)
+                        "--clock-warmup-ms", "0"], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0])
     assert out["n_gpus"] == 2 and out["config"]["chains"] == 2 and out["config"]["collective_backend"] == "gloo" and out["scaling"] == "weak"
     assert out["dtype"] == "f64" and out["fp32"]["dtype"] == "f32" and out["gather_ms"] > 0
     assert out["value"] == pytest.approx(4000 * 12 * 12 * 2 / (out["ms_per_step"] * 1e-3 * 12), rel=1e-6)      # whole-job aggregate over both ranks
     assert out["roofline"]["launches_timed"] >= 8 and out["roofline"]["algorithmic_bytes_per_cell_update"] == 25
+    c4 = out["configs4"]                          # configs[4]'s per-GPU load (rehearsal size), data generated on the device
+    assert c4["value"] > 0 and "nItem=100" in c4["workload"] and "device" in c4["data"]

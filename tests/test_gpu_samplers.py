@@ -43,9 +43,9 @@ def test_pg1_f64_matches_oracle():
 
 def test_pg1_f64_filtered_decisions_are_the_reference_decisions():
     """The fp64 engine's attempt takes its accept / reject decisions in fp32 behind guard bands and evaluates only the accepted value in
-    fp64 (erm_rng.hpp, pg1_attempt(double)).  Against the reference form of the attempt (every statement in fp64) on 2^24 draws:
+    fp64 (erm_rng.hpp, pg1_filter + pg1_value_*).  Against the reference form of the attempt (every statement in fp64) on 2^26 draws:
     a flipped decision would show as a different draw altogether; rounding of the value alone stays below 1e-13."""
-    n = 1 << 22
+    n = 1 << 24
     g = np.random.default_rng(5)
     for k, c in enumerate((g.normal(0, 2.5, n), g.uniform(-3.2, 3.2, n), g.uniform(3.0, 7.0, n), np.concatenate([g.uniform(19.0, 26.0, n // 2), g.uniform(0, 1e-3, n // 2)]))):
         fast, ref = _dev(3, n, c, sweep=11 + k), _dev(10, n, c, sweep=11 + k)
