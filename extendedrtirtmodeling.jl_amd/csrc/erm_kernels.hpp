@@ -649,6 +649,11 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
+#ifndef ERM_SHAREDQ
+#define ERM_SHAREDQ 2
+#endif
+    // ONE cell queue per workgroup in the PG phase instead of one per wave (1: fp64 engine, 2: both engines, 0: off)
+    constexpr bool SHQ = PHASE == 0 && (ERM_SHAREDQ == 2 || (ERM_SHAREDQ == 1 && sizeof(real) == 8));
     const int J = A.J, W = A.W, R = 64 / W, IPL = A.IPL;
     const int F = A.nFeat, p = F + 1;                // design [1 X]
     const int NG = ST::ng(p) + A.ngx;
@@ -975,7 +980,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
         // ---- per-subject values of the global statistics (sums over subjects of products of two of them), parked in LDS and reduced
         // by the whole workgroup after the barrier below (a 64-lane fp64 butterfly per statistic here cost 6 us of the pass):
         // slot c-1 holds value code c: 1..F -> X columns, F+1 theta, F+2 zeta, F+3 u = zeta - k1 nu_{t+1}, F+4 nu_{t+1}
-        if (NG > 1 && rok) {
+        if ((NG > 1 || SHQ) && rok) {
             real* o = sh_val + (size_t)(i - row0) * NV;
             for (int u = 1; u <= F; ++u) o[u - 1] = xcol(u);
             o[F] = th; o[F + 1] = ze; o[F + 2] = ze - k1 * nu_next; o[F + 3] = nu_next;
@@ -991,26 +996,29 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
     // Attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
     if constexpr (PHASE == 0) {
         wave_sync();                                  // sh_th written above
-        const int ncell = (int)(rb - ra) * J;
+        if constexpr (SHQ) { if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(sh_struct + 6) = blockDim.x; __syncthreads(); }
+        const long long qrow0 = SHQ ? row0 : ra;      // first subject of the queue's slice
+        const int ncell = (SHQ ? nrows_blk : (int)(rb - ra)) * J;
+        auto theta_of = [&](int rr_) -> real { if constexpr (SHQ) return sh_val[(size_t)rr_ * NV + F]; else return sh_th[rr_]; };
         const float invJ = 1.0f / (float)J;
         // cells are handed out dynamically from a wave-shared LDS counter: a lane that finishes a cell grabs the next index, so
         // every lane stays busy until the slice is exhausted (which lane draws which cell does not matter: draws are addressed
         // by (i, j, sweep), never by lane)
-        unsigned int* qhead = reinterpret_cast<unsigned int*>(sh_rs);      // the row sums are dead by now
-        if (lane == 0) *qhead = 64u;
+        unsigned int* qhead = SHQ ? reinterpret_cast<unsigned int*>(sh_struct + 6) : reinterpret_cast<unsigned int*>(sh_rs);      // the row sums are dead by now
+        if (!SHQ && lane == 0) *qhead = 64u;
         wave_sync();
         auto locate = [&](int c, int& rr, int& j) {      // c -> (row within slice, item); exact for c < 2^22
             rr = (int)(((float)c + 0.5f) * invJ);
             j = c - rr * J;
             if (j < 0) { j += J; --rr; } else if (j >= J) { j -= J; ++rr; }
         };
-        int c = lane, rr, j;
+        int c = SHQ ? (int)threadIdx.x : lane, rr, j;
         locate(c, rr, j);
         bool active = c < ncell;
         uint32_t att = 0;
-        real th = active ? sh_th[rr] : real(0);
+        real th = active ? theta_of(rr) : real(0);
         real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
-        real* om = A.omega + (size_t)ra * J;
+        real* om = A.omega + (size_t)qrow0 * J;
         const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
         [[maybe_unused]] unsigned int n_att = 0, n_trip = 0;
         // (letting a wave whose queue ran dry serve other waves' queues was tried: the hardware favours a SIMD's oldest wave, so the
@@ -1037,7 +1045,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                 else {
                     int r2, j2;
                     locate(cc, r2, j2);
-                    const double zz = 0.5 * fabs((double)sh_a[j2] * ((double)sh_th[r2] - (double)sh_b[j2]));
+                    const double zz = 0.5 * fabs((double)sh_a[j2] * ((double)theta_of(r2) - (double)sh_b[j2]));
                     if (T == 0) x = pg1_value_tail(zz, e.y, logtab);
                     else x = pg1_value_large(zz >= 1.5625 ? zz : 2.0, e.y, (e.x >> 31) != 0u);
                 }
@@ -1054,7 +1062,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                 uint2 ent = make_uint2(0u, 0u);
                 if (active) {
                     uint32_t w0, w1, w2, w3;
-                    philox4x32_10((uint32_t)(ra + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                    philox4x32_10((uint32_t)(qrow0 + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
                     const PgDecision d = pg1_filter((double)z, w0, w1, w2, w3);
                     bool acc_ = d.accept;
                     if (__any(d.unsure)) {                           // inside a guard band: the reference form decides, and its value is stored at once
@@ -1069,7 +1077,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                         c = (int)atomicAdd(qhead, 1u);
                         att = 0;
                         active = c < ncell;
-                        if (active) { locate(c, rr, j); th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
+                        if (active) { locate(c, rr, j); th = theta_of(rr); z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
                     } else ++att;
                 }
 #pragma unroll
@@ -1092,7 +1100,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 #endif
             if (active) {
                 uint32_t w0, w1, w2, w3;
-                philox4x32_10((uint32_t)(ra + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                philox4x32_10((uint32_t)(qrow0 + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
                 real w;
                 const bool acc_ = pg1_attempt(z, w0, w1, w2, w3, w);
                 if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
@@ -1100,7 +1108,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                     c = (int)atomicAdd(qhead, 1u);
                     att = 0;
                     active = c < ncell;
-                    if (active) { locate(c, rr, j); th = sh_th[rr]; z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
+                    if (active) { locate(c, rr, j); th = theta_of(rr); z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
                 } else ++att;
             }
         }
