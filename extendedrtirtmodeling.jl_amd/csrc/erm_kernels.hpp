@@ -14,6 +14,7 @@
 // reductions are order-deterministic: a chain is bit-reproducible run to run.
 // HBM layout: Y u8 [N][J], centred logT / omega / nu `real` [N][J] (row-major), theta/zeta `real` [N].
 #pragma once
+#include <type_traits>
 #include "erm_rng.hpp"
 
 namespace erm {
@@ -812,7 +813,42 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 
     // =================================================================================================== phase 1 (i)
     // sums over each subject's items; lane (r, s): subject r of the group, items s, s+W, ...
-    if (A.mode == 1) {
+    if (A.mode == 1 && PHASE == 0 && (J & 1) == 0) {
+        // even test lengths: a lane takes PAIRS of neighbouring items (2s, 2s+1), (2(s+W), ...), so that omega and logT come in 16-byte
+        // (fp32: 8-byte) loads and a wave-instruction covers whole 128-byte lines of a row instead of 64-byte halves
+        using real2 = typename std::conditional<sizeof(real) == 8, double2, float2>::type;
+        const int P = J >> 1, IPP = (P + W - 1) / W;
+        for (long long g0 = ra; g0 < rb; g0 += R) {
+            const long long i = g0 + r;
+            const bool rowok = i < rb;
+            const size_t base = (size_t)(rowok ? i : ra) * J;
+            real s0 = 0, s1 = 0, s2 = 0;
+            for (int k0 = 0; k0 < IPP; k0 += KB) {
+                real2 wv[KB], cv[KB]; unsigned int yv[KB]; int jv4[KB]; bool ok4[KB];
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int q = s + W * (k0 + u);
+                    ok4[u] = rowok && (k0 + u) < IPP && q < P;
+                    jv4[u] = ok4[u] ? 2 * q : 0;
+                    const size_t e = base + jv4[u];
+                    wv[u] = *reinterpret_cast<const real2*>(A.omega + e);
+                    yv[u] = *reinterpret_cast<const unsigned short*>(gY + e);
+                    if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const real2*>(gC + e); else { cv[u].x = real(0); cv[u].y = real(0); }
+                }
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int j = jv4[u];
+                    const real m = ok4[u] ? real(1) : real(0);
+                    const real kap0 = (real)(yv[u] & 0xFFu) - real(0.5), kap1 = (real)(yv[u] >> 8) - real(0.5);
+                    s0 += m * (sh_a2[j] * wv[u].x + sh_a2[j + 1] * wv[u].y);
+                    s1 += m * ((sh_a[j] * kap0 + sh_a2b[j] * wv[u].x) + (sh_a[j + 1] * kap1 + sh_a2b[j + 1] * wv[u].y));
+                    if (fam_rt(MODEL) || fam_lq(MODEL)) s2 += m * ((sh_lamc[j] - cv[u].x) * sh_isig[j] + (sh_lamc[j + 1] - cv[u].y) * sh_isig[j + 1]);
+                }
+            }
+            s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W); s1 = bfly_sum(s1, 1, W);
+            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - ra); o[0] = s0; o[1] = s1; o[2] = s2; }
+        }
+    } else if (A.mode == 1) {
         for (long long g0 = ra; g0 < rb; g0 += R) {
             const long long i = g0 + r;
             const bool rowok = i < rb;
