@@ -1211,7 +1211,79 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
     stamp(9);
     // =================================================================================================== phase 2
     // lane = item j; the waves stride over the workgroup's subjects; accumulators live in fp64 registers
-    for (int cb = 0; cb * 64 < J && !ERM_DIAG_ON(A, 7); ++cb) {
+    bool p2_done = false;
+    if constexpr (sizeof(real) == 8 && PHASE == 0 && !fam_cq(MODEL)) {
+        // fp64 engine, even test lengths: a lane takes the item PAIR (2l, 2l+1), the two half-waves take two subjects at a time, so that omega
+        // and logT come in 16-byte loads (the 8-byte loads of one item per lane reach 0.5-0.7 of that rate); lanes l and l + 32 then hold the
+        // sums of different subjects for the same two items and are added at the end
+        if ((J & 1) == 0 && !ERM_DIAG_ON(A, 7)) {
+            p2_done = true;
+            const int half = lane >> 5, l32 = lane & 31;
+            for (int cb = 0; cb * 64 < J; ++cb) {
+                const int j0 = cb * 64 + 2 * l32;
+                const bool jv = j0 < J;
+                const int jc = jv ? j0 : 0;
+                const double a0 = sh_a[jc], a1 = sh_a[jc + 1], b0 = sh_b[jc], b1 = sh_b[jc + 1];
+                const double lamc0 = sh_lamc[jc], lamc1 = sh_lamc[jc + 1], isig0 = sh_isig[jc], isig1 = sh_isig[jc + 1], lsig0 = sh_lsig[jc], lsig1 = sh_lsig[jc + 1];
+                double S0[NSTAT], S1[NSTAT];
+#pragma unroll
+                for (int q = 0; q < NSTAT; ++q) { S0[q] = 0.0; S1[q] = 0.0; }
+                double llc = 0.0;
+                for (long long i0 = row0 + wave; i0 < row1; i0 += 4LL * nWaves) {      // a batch: 2 slots x 2 half-waves = 4 subjects, 4 cells per lane
+                    double thv[2], zev[2]; double2 wv[2], cv[2]; unsigned int yv[2]; bool okv[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const long long i = i0 + (long long)(2 * u + half) * nWaves;
+                        okv[u] = jv && i < row1;
+                        const long long ic = i < row1 ? i : row1 - 1;
+                        const size_t e = (size_t)ic * J + jc;
+                        thv[u] = A.theta[ic];
+                        zev[u] = (MODEL != MLIRT) ? A.zeta[ic] : 0.0;
+                        wv[u] = *reinterpret_cast<const double2*>(A.omega + e);
+                        yv[u] = *reinterpret_cast<const unsigned short*>(gY + e);
+                        if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const double2*>(gC + e); else { cv[u].x = 0.0; cv[u].y = 0.0; }
+                    }
+                    double bs0[NSTAT], bs1[NSTAT], bl = 0.0, bprod = 1.0;
+#pragma unroll
+                    for (int q = 0; q < NSTAT; ++q) { bs0[q] = 0.0; bs1[q] = 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (!okv[u]) continue;
+                        const double th = thv[u], ze = zev[u];
+                        auto cell = [&](double w, bool y, double c, double a, double b, double lamc, double isig, double lsig, double* bs) {
+                            const double wt = w * th;
+                            bs[0] += w; bs[1] += wt; bs[2] += wt * th; bs[3] += y ? 0.5 * th : -0.5 * th;
+                            if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) bs[4] += c * ze;
+                            if (A.mode == 1) {
+                                const double eta = a * (th - b);
+                                double t = (y ? eta : 0.0) - (eta > 0.0 ? eta : 0.0);
+                                bprod *= 1.0 + fm::exp_neg(fabs(eta));
+                                if (fam_rt(MODEL) || fam_lq(MODEL)) {
+                                    const double er = c + ze - lamc;
+                                    t += -0.5 * (LOG_2PI + lsig + er * er * isig);
+                                }
+                                bl += t;
+                            }
+                        };
+                        cell(wv[u].x, (yv[u] & 0xFFu) != 0u, cv[u].x, a0, b0, lamc0, isig0, lsig0, bs0);
+                        cell(wv[u].y, (yv[u] >> 8) != 0u, cv[u].y, a1, b1, lamc1, isig1, lsig1, bs1);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NSTAT; ++q) { S0[q] += bs0[q]; S1[q] += bs1[q]; }
+                    if (A.mode == 1) bl -= fm::log(bprod, logtab);
+                    llc += bl;
+                }
+#pragma unroll
+                for (int q = 0; q < NSTAT; ++q) { S0[q] += __shfl_xor(S0[q], 32, 64); S1[q] += __shfl_xor(S1[q], 32, 64); }
+                if (jv && half == 0) {
+#pragma unroll
+                    for (int q = 0; q < NSTAT; ++q) { acc[q * J + j0] = S0[q]; acc[q * J + j0 + 1] = S1[q]; }
+                }
+                ll += llc;
+            }
+        }
+    }
+    for (int cb = 0; cb * 64 < J && !ERM_DIAG_ON(A, 7) && !p2_done; ++cb) {
         const int j = cb * 64 + lane;
         const bool jv = j < J;
         const real a = jv ? sh_a[j] : real(0), b = jv ? sh_b[j] : real(0);
