@@ -813,7 +813,10 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 
     // =================================================================================================== phase 1 (i)
     // sums over each subject's items; lane (r, s): subject r of the group, items s, s+W, ...
-    if (A.mode == 1 && PHASE == 0 && sizeof(real) == 8 && (J & 1) == 0) {
+#ifndef ERM_PAIRS_F32
+#define ERM_PAIRS_F32 0
+#endif
+    if (A.mode == 1 && PHASE == 0 && (sizeof(real) == 8 || ERM_PAIRS_F32) && (J & 1) == 0) {
         // fp64 engine, even test lengths: a lane takes PAIRS of neighbouring items (2s, 2s+1), (2(s+W), ...), so that omega and logT come in
         // 16-byte loads and a wave-instruction covers whole 128-byte lines of a row instead of 64-byte halves (120.4 -> 113.9 us per sweep;
         // the fp32 engine's 8-byte pairs gained nothing and stay on the scalar path)
