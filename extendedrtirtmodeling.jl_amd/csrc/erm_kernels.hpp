@@ -1359,7 +1359,9 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                     if (A.mode == 1) {
                         const real var_ = k2 * nu;                               // times sig2t_j
                         const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
-                        bl += real(-0.5) * ((real)LOG_2PI + lsig + r_log(var_) + r_div(er * er * isig, var_));
+                        real lv;
+                        if constexpr (sizeof(real) == 8) lv = fm::log(var_, logtab); else lv = r_log(var_);       // var_ = k2 nu in [1e-10 k2, 1e10 k2]
+                        bl += real(-0.5) * ((real)LOG_2PI + lsig + lv + r_div(er * er * isig, var_));
                         if (has_nu(MODEL) && post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
                         if (has_nu(MODEL) && A.tr_nu) A.tr_nu[(size_t)trow * (size_t)A.N * J + e] = nu;     // Post.qr's vec(nu_t) (src/GibbsRtIrtCross.pl.jl:296)
                     }
@@ -1755,11 +1757,12 @@ __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uin
     double v = 0.0;
     switch (which) {
     case 15: v = fm::log(par0[k], sh_logtab); break;           // the table form of the cell path's logarithm
+    case 16: v = fm::cos2pi(par0[k]); break;
     case 0: v = (double)uniform<real>(st); break;
     case 1: v = (double)normal<real>(st); break;
     case 2: v = (double)expo<real>(st); break;
     case 3: v = (double)pg1<real>(st, (real)par0[k]); break;
-    case 4: v = (double)invgauss<real>(st, (real)par0[k], (real)par1[k]); break;
+    case 4: v = (double)invgauss(st, (real)par0[k], (real)par1[k]); break;
     case 5: v = truncnorm0(st, par0[k], par1[k]); break;
     case 6: v = gamma_mt(st, par0[k]); break;
     case 7: { const real z = (real)par0[k]; v = (double)pg_tail_weight<real>(z, real(0.125) * Const<real>::PI * Const<real>::PI + real(0.5) * z * z); } break;

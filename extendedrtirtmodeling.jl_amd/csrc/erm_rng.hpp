@@ -106,6 +106,24 @@ __device__ __forceinline__ double log(double x, const double2* tab)
     const double l1p = fma(P * r, r, r);
     return fma((double)e, 0.693147180559945309417, t.y) + l1p;
 }
+// cos(2 pi u), u in [0, 1]: u = k/4 + r with k = rint(4u) and |r| <= 1/8 revolutions, i.e. phi = 2 pi r in [-pi/4, pi/4];
+// cos(2 pi u) = cos(phi + k pi/2) = {cos, -sin, -cos, sin}(phi) for k mod 4 = 0..3; Taylor polynomials to phi^16 / phi^15 (next terms < 5e-17).
+// ~30 instructions against 66 for OCML's cospi.
+__device__ __forceinline__ double cos2pi(double u)
+{
+    const double k = __builtin_rint(4.0 * u);
+    const double phi = 6.28318530717958647692 * fma(-0.25, k, u);        // exact reduction: 4u and k are exact for u = (w + 1/2) 2^-32
+    const double z = phi * phi;
+    double c = 1.0 / 20922789888000.0;                                    // cos: sum (-1)^n z^n / (2n)!
+    c = fma(c, z, -1.0 / 87178291200.0); c = fma(c, z, 1.0 / 479001600.0); c = fma(c, z, -1.0 / 3628800.0); c = fma(c, z, 1.0 / 40320.0);
+    c = fma(c, z, -1.0 / 720.0); c = fma(c, z, 1.0 / 24.0); c = fma(c, z, -0.5); c = fma(c, z, 1.0);
+    double sn = -1.0 / 1307674368000.0;                                   // sin: phi sum (-1)^n z^n / (2n+1)!
+    sn = fma(sn, z, 1.0 / 6227020800.0); sn = fma(sn, z, -1.0 / 39916800.0); sn = fma(sn, z, 1.0 / 362880.0); sn = fma(sn, z, -1.0 / 5040.0);
+    sn = fma(sn, z, 1.0 / 120.0); sn = fma(sn, z, -1.0 / 6.0); sn = fma(sn * z, phi, phi);
+    const int q = (int)k & 3;
+    const double v = (q & 1) ? sn : c;
+    return (q == 0 || q == 3) ? v : -v;
+}
 // e^{-a}, 0 <= a (-> 0 beyond 700): a = k ln2 + r, |r| <= ln2/2, Taylor series of e^{-r} to r^13/13! (4e-18), scaled by 2^-k
 __device__ __forceinline__ double exp_neg(double a)
 {
@@ -190,6 +208,14 @@ template <typename real> __device__ __forceinline__ real normal(Stream& s)
     return r_sqrt(real(-2) * r_log(u1)) * r_cos2pi(u2);
 }
 
+// fp64 cell path: the same variate from the range-specialised functions (uniforms are normal, finite numbers in (0, 1))
+__device__ __forceinline__ double normal_sq_fast(Stream& s)      // N(0,1)^2 = -2 log(u1) cos^2(2 pi u2): the IG draw needs only the square
+{
+    const double u1 = uniform<double>(s), u2 = uniform<double>(s);
+    const double c = fm::cos2pi(u2);
+    return -2.0 * fm::log(u1) * (c * c);
+}
+
 // IG(mu, lambda), Michael-Schucany-Haas.  With y = N^2 and w = mu y the smaller root mu + mu/(2 lambda)(w - sqrt(w (4 lambda + w)))
 // is evaluated as 4 lambda / (y (1 + sqrt(1 + 4 lambda / w))^2): no cancellation, no overflow, and the correct limits
 // x1 -> lambda / y (Levy) as mu -> inf and x1 -> mu as y -> 0.  The first root is kept with probability mu/(mu + x1) = 1/(1 + x1/mu).
@@ -204,12 +230,24 @@ template <typename real> __device__ __forceinline__ real invgauss(Stream& s, rea
     return (u >= r_rcp(real(1) + x1 * r_rcp(mu))) ? r_div(mu * mu, x1) : x1;
 }
 
+// fp64 overload: y = N^2 without the square root, log and cosine from namespace fm; the divisions and the inner square root keep IEEE semantics
+// (mu = inf, y -> 0 and w -> 0 must give the documented limits)
+__device__ __forceinline__ double invgauss(Stream& s, double mu, double lambda)
+{
+    const double y = normal_sq_fast(s);
+    const double w = mu * y;
+    const double t = 1.0 + sqrt(1.0 + 4.0 * lambda / w);
+    const double x1 = 4.0 * lambda / (y * t * t);
+    const double u = uniform<double>(s);
+    return (u >= 1.0 / (1.0 + x1 / mu)) ? mu * mu / x1 : x1;
+}
+
 // nu = clamp(1 / IG(clamp(parB/parA, 1e-10, Inf), parB^2), 1e-10, 1e10): src/Draw.pl.jl:310-318, 333-341
 template <typename real> __device__ __forceinline__ real qr_weight(Stream& s, real parA, real parB)
 {
     real mu = r_div(parB, parA);
     mu = mu < real(1e-10) ? real(1e-10) : mu;
-    real nu = r_rcp(invgauss<real>(s, mu, parB * parB));
+    real nu = r_rcp(invgauss(s, mu, real(parB * parB)));
     nu = nu < real(1e-10) ? real(1e-10) : (nu > real(1e10) ? real(1e10) : nu);
     return nu;
 }

@@ -80,6 +80,10 @@ def test_fp64_cell_path_elementary_functions():
     assert np.max(np.abs(d - ref) / ref) < 2e-15
     d = _dev(13, x.size, x)
     assert np.max(np.abs(d - np.sqrt(x)) / np.sqrt(x)) < 3e-16
+    u = np.concatenate([g.uniform(0, 1, N), (np.arange(0, 4097) / 4096.0), (np.arange(0, 2 ** 12) + 0.5) * 2.0 ** -32, 1 - (np.arange(0, 2 ** 12) + 0.5) * 2.0 ** -32])
+    d = _dev(16, u.size, u)
+    ref = np.cos(2 * np.longdouble("3.14159265358979323846264338327950288") * u.astype(np.longdouble)).astype(np.float64)      # 80-bit argument: 2 pi u in double is already off by 7e-16
+    assert np.max(np.abs(d - ref)) < 3e-16
     y = 10.0 ** g.uniform(-6, 6, x.size) * g.choice([-1.0, 1.0], x.size)
     d = _dev(14, x.size, y, x)
     assert np.max(np.abs(d - y / x) / np.abs(y / x)) < 3e-16
