@@ -1012,7 +1012,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
             const real parA = r_div(r_abs(ze - xb5), den);
             const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
             Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i + A.row_base, 0u, sweep + 1u);
-            nu_next = qr_weight<real>(st, parA, parB);
+            nu_next = qr_weight<real>(st, parA, parB, logtab);
             if (rok) A.nu[i] = nu_next;
         }
         if (PHASE == 0 && rok) sh_th[li] = th;
@@ -1361,7 +1361,9 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                         const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
                         real lv;
                         if constexpr (sizeof(real) == 8) lv = fm::log(var_, logtab); else lv = r_log(var_);       // var_ = k2 nu in [1e-10 k2, 1e10 k2]
-                        bl += real(-0.5) * ((real)LOG_2PI + lsig + lv + r_div(er * er * isig, var_));
+                        real qv;
+                        if constexpr (sizeof(real) == 8) qv = fm::div(er * er * isig, var_); else qv = r_div(er * er * isig, var_);       // var_ is a normal, finite number
+                        bl += real(-0.5) * ((real)LOG_2PI + lsig + lv + qv);
                         if (has_nu(MODEL) && post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
                         if (has_nu(MODEL) && A.tr_nu) A.tr_nu[(size_t)trow * (size_t)A.N * J + e] = nu;     // Post.qr's vec(nu_t) (src/GibbsRtIrtCross.pl.jl:296)
                     }
@@ -1371,10 +1373,11 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                     real nun = real(1);
                     if constexpr (has_nu(MODEL)) {
                         Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i + A.row_base, (uint32_t)j, sweep + 1u);
-                        nun = qr_weight<real>(st, parA, parB);
+                        nun = qr_weight<real>(st, parA, parB, logtab);
                         A.nu[e] = nun;
                     }
-                    const real ti = th * r_rcp(nun);
+                    real ti;
+                    if constexpr (sizeof(real) == 8) ti = th * fm::rcp(nun); else ti = th * r_rcp(nun);      // nu_{t+1} is clamped to [1e-10, 1e10]
                     bs[0] += th * ti;
                     bs[1] += (lamc - ze - c + k1 * nun) * ti;
                 }

@@ -209,11 +209,11 @@ template <typename real> __device__ __forceinline__ real normal(Stream& s)
 }
 
 // fp64 cell path: the same variate from the range-specialised functions (uniforms are normal, finite numbers in (0, 1))
-__device__ __forceinline__ double normal_sq_fast(Stream& s)      // N(0,1)^2 = -2 log(u1) cos^2(2 pi u2): the IG draw needs only the square
+__device__ __forceinline__ double normal_sq_fast(Stream& s, const double2* tab = nullptr)      // N(0,1)^2 = -2 log(u1) cos^2(2 pi u2): the IG draw needs only the square
 {
     const double u1 = uniform<double>(s), u2 = uniform<double>(s);
     const double c = fm::cos2pi(u2);
-    return -2.0 * fm::log(u1) * (c * c);
+    return -2.0 * (tab ? fm::log(u1, tab) : fm::log(u1)) * (c * c);
 }
 
 // IG(mu, lambda), Michael-Schucany-Haas.  With y = N^2 and w = mu y the smaller root mu + mu/(2 lambda)(w - sqrt(w (4 lambda + w)))
@@ -232,9 +232,9 @@ template <typename real> __device__ __forceinline__ real invgauss(Stream& s, rea
 
 // fp64 overload: y = N^2 without the square root, log and cosine from namespace fm; the divisions and the inner square root keep IEEE semantics
 // (mu = inf, y -> 0 and w -> 0 must give the documented limits)
-__device__ __forceinline__ double invgauss(Stream& s, double mu, double lambda)
+__device__ __forceinline__ double invgauss(Stream& s, double mu, double lambda, const double2* tab = nullptr)
 {
-    const double y = normal_sq_fast(s);
+    const double y = normal_sq_fast(s, tab);
     const double w = mu * y;
     const double t = 1.0 + sqrt(1.0 + 4.0 * lambda / w);
     const double x1 = 4.0 * lambda / (y * t * t);
@@ -243,11 +243,12 @@ __device__ __forceinline__ double invgauss(Stream& s, double mu, double lambda)
 }
 
 // nu = clamp(1 / IG(clamp(parB/parA, 1e-10, Inf), parB^2), 1e-10, 1e10): src/Draw.pl.jl:310-318, 333-341
-template <typename real> __device__ __forceinline__ real qr_weight(Stream& s, real parA, real parB)
+template <typename real> __device__ __forceinline__ real qr_weight(Stream& s, real parA, real parB, [[maybe_unused]] const double2* tab = nullptr)
 {
     real mu = r_div(parB, parA);
     mu = mu < real(1e-10) ? real(1e-10) : mu;
-    real nu = r_rcp(invgauss(s, mu, real(parB * parB)));
+    real nu;
+    if constexpr (sizeof(real) == 8) nu = r_rcp(invgauss(s, mu, parB * parB, tab)); else nu = r_rcp(invgauss(s, mu, real(parB * parB)));
     nu = nu < real(1e-10) ? real(1e-10) : (nu > real(1e10) ? real(1e10) : nu);
     return nu;
 }
