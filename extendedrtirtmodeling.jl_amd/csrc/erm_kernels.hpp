@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 #ifndef ERM_PAIRS_F32
 #define ERM_PAIRS_F32 0
 #endif
-    if (A.mode == 1 && PHASE == 0 && (sizeof(real) == 8 || ERM_PAIRS_F32) && (J & 1) == 0) {
+    if (A.mode == 1 && (sizeof(real) == 8 || ERM_PAIRS_F32) && (J & 1) == 0) {
         // fp64 engine, even test lengths: a lane takes PAIRS of neighbouring items (2s, 2s+1), (2(s+W), ...), so that omega and logT come in
         // 16-byte loads and a wave-instruction covers whole 128-byte lines of a row instead of 64-byte halves (120.4 -> 113.9 us per sweep;
         // the fp32 engine's 8-byte pairs gained nothing and stay on the scalar path)
@@ -827,6 +827,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
             const bool rowok = i < rb;
             const size_t base = (size_t)(rowok ? i : ra) * J;
             real s0 = 0, s1 = 0, s2 = 0;
+            const real thr = (PHASE == 1 && rowok) ? A.theta[i] : real(0);
             for (int k0 = 0; k0 < IPP; k0 += KB) {
                 real2 wv[KB], cv[KB]; unsigned int yv[KB]; int jv4[KB]; bool ok4[KB];
 #pragma unroll
@@ -835,21 +836,29 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
                     ok4[u] = rowok && (k0 + u) < IPP && q < P;
                     jv4[u] = ok4[u] ? 2 * q : 0;
                     const size_t e = base + jv4[u];
-                    wv[u] = *reinterpret_cast<const real2*>(A.omega + e);
-                    yv[u] = *reinterpret_cast<const unsigned short*>(gY + e);
+                    if constexpr (PHASE == 0) { wv[u] = *reinterpret_cast<const real2*>(A.omega + e); yv[u] = *reinterpret_cast<const unsigned short*>(gY + e); }
+                    else { yv[u] = 0u; if constexpr (has_nu(MODEL)) wv[u] = *reinterpret_cast<const real2*>(A.nu + e); else { wv[u].x = real(1); wv[u].y = real(1); } }
                     if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const real2*>(gC + e); else { cv[u].x = real(0); cv[u].y = real(0); }
                 }
 #pragma unroll
                 for (int u = 0; u < KB; ++u) {
                     const int j = jv4[u];
                     const real m = ok4[u] ? real(1) : real(0);
-                    const real kap0 = (real)(yv[u] & 0xFFu) - real(0.5), kap1 = (real)(yv[u] >> 8) - real(0.5);
-                    s0 += m * (sh_a2[j] * wv[u].x + sh_a2[j + 1] * wv[u].y);
-                    s1 += m * ((sh_a[j] * kap0 + sh_a2b[j] * wv[u].x) + (sh_a[j + 1] * kap1 + sh_a2b[j + 1] * wv[u].y));
-                    if (fam_rt(MODEL) || fam_lq(MODEL)) s2 += m * ((sh_lamc[j] - cv[u].x) * sh_isig[j] + (sh_lamc[j + 1] - cv[u].y) * sh_isig[j + 1]);
+                    if constexpr (PHASE == 0) {
+                        const real kap0 = (real)(yv[u] & 0xFFu) - real(0.5), kap1 = (real)(yv[u] >> 8) - real(0.5);
+                        s0 += m * (sh_a2[j] * wv[u].x + sh_a2[j + 1] * wv[u].y);
+                        s1 += m * ((sh_a[j] * kap0 + sh_a2b[j] * wv[u].x) + (sh_a[j + 1] * kap1 + sh_a2b[j + 1] * wv[u].y));
+                        if (fam_rt(MODEL) || fam_lq(MODEL)) s2 += m * ((sh_lamc[j] - cv[u].x) * sh_isig[j] + (sh_lamc[j + 1] - cv[u].y) * sh_isig[j + 1]);
+                    } else {   // Cross family pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202)
+                        const real nu0 = ok4[u] ? wv[u].x : real(1), nu1 = ok4[u] ? wv[u].y : real(1);
+                        const real id0 = r_div(sh_isig[j], k2 * nu0), id1 = r_div(sh_isig[j + 1], k2 * nu1);
+                        s0 += m * (id0 + id1);
+                        s2 += m * ((sh_lamc[j] - cv[u].x - thr * sh_rho[j] + k1 * nu0) * id0 + (sh_lamc[j + 1] - cv[u].y - thr * sh_rho[j + 1] + k1 * nu1) * id1);
+                    }
                 }
             }
-            s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W); s1 = bfly_sum(s1, 1, W);
+            s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W);
+            if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
             if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - ra); o[0] = s0; o[1] = s1; o[2] = s2; }
         }
     } else if (A.mode == 1) {
