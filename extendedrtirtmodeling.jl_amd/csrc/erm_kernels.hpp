@@ -1222,7 +1222,9 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 
     stamp(9);
     // =================================================================================================== phase 2
-    // lane = item j; the waves stride over the workgroup's subjects; accumulators live in fp64 registers
+    // lane = item j; a wave takes the subjects of its own slice [ra, rb) from the LAST to the first, so that the phase ends on the rows the
+    // next sweep's row sums read first: the workgroup's share of its XCD's L2 (128 KB) holds that part of the slice (fp64: 332 KB at
+    // 100 000 x 50) from one launch to the next; accumulators live in fp64 registers
     bool p2_done = false;
     if constexpr (sizeof(real) == 8 && PHASE == 0 && !fam_cq(MODEL)) {
         // fp64 engine, even test lengths: a lane takes the item PAIR (2l, 2l+1), the two half-waves take two subjects at a time, so that omega
@@ -1241,13 +1243,13 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
 #pragma unroll
                 for (int q = 0; q < NSTAT; ++q) { S0[q] = 0.0; S1[q] = 0.0; }
                 double llc = 0.0;
-                for (long long i0 = row0 + wave; i0 < row1; i0 += 4LL * nWaves) {      // a batch: 2 slots x 2 half-waves = 4 subjects, 4 cells per lane
+                for (long long i0 = rb - 1; i0 >= ra; i0 -= 4) {      // a batch: 2 slots x 2 half-waves = 4 subjects, 4 cells per lane
                     double thv[2], zev[2]; double2 wv[2], cv[2]; unsigned int yv[2]; bool okv[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const long long i = i0 + (long long)(2 * u + half) * nWaves;
-                        okv[u] = jv && i < row1;
-                        const long long ic = i < row1 ? i : row1 - 1;
+                        const long long i = i0 - (2 * u + half);
+                        okv[u] = jv && i >= ra;
+                        const long long ic = i >= ra ? i : ra;
                         const size_t e = (size_t)ic * J + jc;
                         thv[u] = A.theta[ic];
                         zev[u] = (MODEL != MLIRT) ? A.zeta[ic] : 0.0;
@@ -1306,13 +1308,13 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
         for (int q = 0; q < NSTAT; ++q) S[q] = 0.0;
         double llc = 0.0;
         const int jc = jv ? j : 0;
-        for (long long i0 = row0 + wave; i0 < row1; i0 += 4LL * nWaves) {
+        for (long long i0 = rb - 1; i0 >= ra; i0 -= 4) {
             real thv[4], zev[4], wv[4], cv[4], nv[4]; bool yv[4], okv[4]; long long iv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                 // every load of the batch is issued before any use
-                const long long i = i0 + (long long)u * nWaves;
-                okv[u] = jv && i < row1;
-                iv[u] = i < row1 ? i : row1 - 1;
+                const long long i = i0 - u;
+                okv[u] = jv && i >= ra;
+                iv[u] = i >= ra ? i : ra;
                 const size_t e = (size_t)iv[u] * J + jc;
                 thv[u] = A.theta[iv[u]];
                 zev[u] = (MODEL != MLIRT) ? A.zeta[iv[u]] : real(0);
