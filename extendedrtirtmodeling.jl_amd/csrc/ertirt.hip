@@ -295,7 +295,8 @@ template <typename real> struct Engine : EngineBase {
             if (fused() && nWaves > 1) rows_per_wave = (int)((rows_per_block + nWaves - 2) / (nWaves - 1)) + 1;
             for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
             const size_t need_lds = std::max(std::max(lds_pass[0], lds_pass[1]), fused() ? fused_lds() : (size_t)0);
-            if (need_lds <= 158 * 1024 || cfg.grid_blocks > 0 || rows_per_block <= nWaves) {
+            const bool cells_ok = rows_per_block * J < ((int64_t)1 << 22);      // the PG phase's cell indices (erm_kernels.hpp, `locate`: exact below 2^22)
+            if ((need_lds <= 158 * 1024 && cells_ok) || cfg.grid_blocks > 0 || rows_per_block <= nWaves) {
                 // more workgroups than the chip holds at once run in rounds: fill the last round (a partial one costs as much as a full one)
                 const int slots = cu_count * per_cu;
                 if (cfg.grid_blocks == 0 && grid_blocks > slots && grid_blocks % slots != 0 && !rounded) {
@@ -314,6 +315,7 @@ template <typename real> struct Engine : EngineBase {
             for (int ph = 0; ph < 2; ++ph) lds_pass[ph] = pass_lds(ph, nWaves);
         }
         if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads or raise grid_blocks");
+        if (rows_per_block * J >= ((int64_t)1 << 22)) return fail(ERM_ERR_ARG, "a workgroup would own 2^22 cells or more; raise grid_blocks");
 
         // ---- device memory
         rows_cap = (int64_t)cfg.n_iter * cfg.n_chain;
