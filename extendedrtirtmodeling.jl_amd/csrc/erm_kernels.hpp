@@ -1223,8 +1223,8 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_
     stamp(9);
     // =================================================================================================== phase 2
     // lane = item j; a wave takes the subjects of its own slice [ra, rb) from the LAST to the first, so that the phase ends on the rows the
-    // next sweep's row sums read first: the workgroup's share of its XCD's L2 (128 KB) holds that part of the slice (fp64: 332 KB at
-    // 100 000 x 50) from one launch to the next; accumulators live in fp64 registers
+    // next sweep's row sums read first (A/B on one box: 109.7 -> 108.9 us per sweep; FETCH_SIZE is unchanged -- the L2s of a multi-XCD part
+    // are written back and invalidated between launches -- so the gain is the memory side's); accumulators live in fp64 registers
     bool p2_done = false;
     if constexpr (sizeof(real) == 8 && PHASE == 0 && !fam_cq(MODEL)) {
         // fp64 engine, even test lengths: a lane takes the item PAIR (2l, 2l+1), the two half-waves take two subjects at a time, so that omega
