@@ -117,8 +117,10 @@ __device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + lo
 #define ERM_F32_THREADS 1024     // threads per workgroup of the fp32 engine = the register budget the row-pass kernel is compiled for (128 VGPRs)
 #endif
 #ifndef ERM_F64_THREADS
-#define ERM_F64_THREADS 768      // fp64 engine: 12 waves per CU (3 per SIMD), 168 VGPRs each -- ONE workgroup per CU, like the fp32 engine
-#endif
+#define ERM_F64_THREADS 1024     // fp64 engine: 16 waves per CU (4 per SIMD), 128 VGPRs each -- ONE workgroup per CU, like the fp32 engine.  A/B on one box against 768
+#endif                           // threads (168 VGPRs, no spills): RtIrt 111.6 -> 106.7 us, MlIrt 98.2 -> 92.8, 500 000 x 100 922 -> 883; the 13-18 spilled registers
+                                 // are loop-invariant fp64 constants re-read by one queue evaluation.  LatentQr (72 spills at 128 VGPRs: 103.6 -> 113.0 us) stays at 768.
+#define ERM_F64_THREADS_LATENTQR 768
 constexpr double LOG_2PI = 1.8378770664093454836;
 constexpr int GROUP = 16;  // workgroups whose slab rows are summed by the last of them to finish
 constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
@@ -646,7 +648,7 @@ __device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* pa
 // (T.par_out, T.ctl_out, traces).  Inputs and outputs are distinct (double-buffered) allocations, so a workgroup that starts late
 // never sees a half-updated block.  That removes one kernel boundary and the tiny kernel's cold start from every sweep.
 template <int MODEL, typename real, int PHASE, bool FUSED>
-__global__ void __launch_bounds__(sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_THREADS) pass_kernel(PassArgs<real> A, TinyArgs T)
+__global__ void __launch_bounds__(sizeof(real) == 8 ? (MODEL == LATENTQR ? ERM_F64_THREADS_LATENTQR : ERM_F64_THREADS) : ERM_F32_THREADS) pass_kernel(PassArgs<real> A, TinyArgs T)
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;

@@ -267,9 +267,9 @@ template <typename real> struct Engine : EngineBase {
         }
         logW = 0; while ((1 << logW) < W) ++logW;
         IPL = (J + W - 1) / W;
-        const int max_threads = sizeof(real) == 8 ? ERM_F64_THREADS : ERM_F32_THREADS;
+        const int max_threads = sizeof(real) == 8 ? (cfg.model == ERM_MODEL_LATENTQR ? ERM_F64_THREADS_LATENTQR : ERM_F64_THREADS) : ERM_F32_THREADS;      // = the kernels' launch bounds
         block_threads = cfg.block_threads > 0 ? cfg.block_threads : max_threads;
-        if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= " + std::to_string(ERM_F32_THREADS) + " (fp32) / " + std::to_string(ERM_F64_THREADS) + " (fp64)");
+        if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= " + std::to_string(max_threads) + " for this model and precision");
         // the per-wave item accumulators (nWaves x NSTAT x nItem doubles) dominate LDS for long tests: fewer waves per workgroup then
         if (cfg.block_threads == 0) {
             while (block_threads > 64) {
