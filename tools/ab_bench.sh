@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of library builds on ONE box (box-to-box spread on the pool is +-1.5 %): alternating runs of the default bench.
 # usage (on the GPU box, from the repo root): bash tools/ab_bench.sh [bench args ...] -- libA.so libB.so ...   ("-" = the in-tree library)
+# NB "-" is the working tree AS SNAPSHOT: bench.py rebuilds the in-tree library when a source is newer than it, so an edited tree is measured as edited --
+# build the edit as a variant (tools/build_variant.sh), put the tree back, then compare "-" with the variant.
 ARGS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do ARGS+=("$1"); shift; done; shift
 for k in 1 2 3; do
   for L in "$@"; do
