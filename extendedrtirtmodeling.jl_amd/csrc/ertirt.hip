@@ -286,7 +286,9 @@ template <typename real> struct Engine : EngineBase {
         if (grid_blocks < 1) grid_blocks = 1;
         // each workgroup owns a contiguous range of subjects, split evenly over its waves
         // (the per-subject LDS caches grow with the rows a workgroup owns: very long data sets get more workgroups than CUs)
-        bool rounded = false;
+        // (more workgroups than the chip holds at once run in rounds, and a partial round costs as much as a full one: past one round the count
+        // grows by whole rounds -- the smallest number of rounds whose workgroups fit their subjects into LDS)
+        const int slots = cu_count * per_cu;
         for (;;) {
             rows_per_block = (N + grid_blocks - 1) / grid_blocks;
             grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
@@ -294,19 +296,16 @@ template <typename real> struct Engine : EngineBase {
             // fused sweeps take subjects off wave 0 (it runs the tiny step's structural chain first): the other waves' slices grow
             if (fused() && nWaves > 1) rows_per_wave = (int)((rows_per_block + nWaves - 2) / (nWaves - 1)) + 1;
             for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
-            const size_t need_lds = std::max(std::max(lds_pass[0], lds_pass[1]), fused() ? fused_lds() : (size_t)0);
+            // one round: the fused sweep kernel (tiny step in every workgroup's head) must fit as well.  Several rounds: only the row pass must -- the
+            // fewest rounds win (500 000 x 100 in fp64: 2 rounds of 512 workgroups 857 us, 4 rounds 884; 2 000 000 x 50: 8 rounds 1 829 us, 12 rounds
+            // 1 999), and when the tiny step's scratch no longer fits beside the larger slices the sweep falls back to the two-kernel schedule below
+            const bool one_round = grid_blocks <= slots;
+            const size_t need_lds = std::max(std::max(lds_pass[0], lds_pass[1]), (one_round && fused()) ? fused_lds() : (size_t)0);
             const bool cells_ok = rows_per_block * J < ((int64_t)1 << 22);      // the PG phase's cell indices (erm_kernels.hpp, `locate`: exact below 2^22)
-            if ((need_lds <= 158 * 1024 && cells_ok) || cfg.grid_blocks > 0 || rows_per_block <= nWaves) {
-                // more workgroups than the chip holds at once run in rounds: fill the last round (a partial one costs as much as a full one)
-                const int slots = cu_count * per_cu;
-                if (cfg.grid_blocks == 0 && grid_blocks > slots && grid_blocks % slots != 0 && !rounded) {
-                    rounded = true;
-                    grid_blocks = (grid_blocks + slots - 1) / slots * slots;
-                    continue;
-                }
-                break;
-            }
-            grid_blocks += std::max(1, grid_blocks / 4);          // every extra round of workgroups costs a head and a tail: grow gently
+            if ((need_lds <= 158 * 1024 && cells_ok) || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
+            // (the count above is the smallest with that many subjects per workgroup -- 767, not 768: whole rounds are counted rounding up)
+            if (grid_blocks >= slots) grid_blocks = ((grid_blocks + slots - 1) / slots + 1) * slots;
+            else grid_blocks = std::min(slots, grid_blocks + std::max(1, grid_blocks / 4));
         }
         if (getenv("ERM_NO_FUSE")) fuse_ok = false;                       // diagnostics: the two-kernel schedule (stand-alone tiny kernel)
         if (!fuse_ok || (fused() && fused_lds() > 160 * 1024)) {       // the tiny step's scratch does not fit next to the pass layout (or ERM_NO_FUSE): keep the two-kernel schedule
