@@ -296,11 +296,10 @@ template <typename real> struct Engine : EngineBase {
             // fused sweeps take subjects off wave 0 (it runs the tiny step's structural chain first): the other waves' slices grow
             if (fused() && nWaves > 1) rows_per_wave = (int)((rows_per_block + nWaves - 2) / (nWaves - 1)) + 1;
             for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
-            // one round: the fused sweep kernel (tiny step in every workgroup's head) must fit as well.  Several rounds: only the row pass must -- the
-            // fewest rounds win (500 000 x 100 in fp64: 2 rounds of 512 workgroups 857 us, 4 rounds 884; 2 000 000 x 50: 8 rounds 1 829 us, 12 rounds
-            // 1 999), and when the tiny step's scratch no longer fits beside the larger slices the sweep falls back to the two-kernel schedule below
-            const bool one_round = grid_blocks <= slots;
-            const size_t need_lds = std::max(std::max(lds_pass[0], lds_pass[1]), (one_round && fused()) ? fused_lds() : (size_t)0);
+            // only the row pass has to fit: the fewest rounds win (fp64, 200 000 x 50: one round 195 us, two 212; 500 000 x 100: 2 rounds 857 us, 4 rounds
+            // 884; 2 000 000 x 50: 8 rounds 1 829 us, 12 rounds 1 999).  When the tiny step's scratch no longer fits beside the larger slices the sweep
+            // falls back to the two-kernel schedule below (tiny step in a kernel of its own instead of every workgroup's head)
+            const size_t need_lds = std::max(lds_pass[0], lds_pass[1]);
             const bool cells_ok = rows_per_block * J < ((int64_t)1 << 22);      // the PG phase's cell indices (erm_kernels.hpp, `locate`: exact below 2^22)
             if ((need_lds <= 158 * 1024 && cells_ok) || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
             // (the count above is the smallest with that many subjects per workgroup -- 767, not 768: whole rounds are counted rounding up)
