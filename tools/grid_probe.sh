@@ -2,7 +2,7 @@
 # workgroup counts tried on one configuration (GPU box): bash tools/grid_probe.sh <nsubj> <nitem> <grid> [<grid> ...]   (0 = the library's own choice)
 N=$1; J=$2; shift 2
 for g in "$@"; do
-  python bench.py --no-fp32 --cpu-sweeps 0 --nsubj $N --nitem $J --steps 200 --warmup 20 --grid-blocks $g 2>&1 | tail -1 | python -c "
+  python bench.py --precision ${PREC:-f64} --no-fp32 --cpu-sweeps 0 --nsubj $N --nitem $J --steps 200 --warmup 20 --grid-blocks $g 2>&1 | tail -1 | python -c "
 import sys, json
 l = sys.stdin.readline()
 try:
