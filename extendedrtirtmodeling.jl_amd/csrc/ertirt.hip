@@ -72,6 +72,8 @@ Rccl g_rccl;
         if (r__ != ncclSuccess) return fail(ERM_ERR_STATE, std::string(#expr) + ": " + g_rccl.GetErrorString(r__)); \
     } while (0)
 
+// host -> device, complete on return for EVERY stream: the copy runs on the NULL stream, with which the engines' non-blocking streams are not ordered
+#define H2D(dst, src, n) do { HIPCHK(hipMemcpy((dst), (src), (n), hipMemcpyHostToDevice)); HIPCHK(hipStreamSynchronize(nullptr)); } while (0)
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -80,7 +82,11 @@ struct DevBuf {
         bytes = n;
         if (n == 0) return 0;
         HIPCHK(hipMalloc(&p, n));
+        // hipMemset on device memory is asynchronous with respect to the host and runs on the NULL stream, with which the engines' non-blocking
+        // streams are not ordered: a kernel enqueued next on an engine stream could write the buffer before (and be wiped by) the fill.  Seen as
+        // a farm chain whose data constants were off about once in 500 runs, with three host threads in erm_set_data at once.
         HIPCHK(hipMemset(p, 0, n));
+        HIPCHK(hipStreamSynchronize(nullptr));
         return 0;
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -279,6 +285,18 @@ template <typename real> struct Engine : EngineBase {
                 block_threads = std::max(64, block_threads / 2 / 64 * 64);
             }
         }
+        // small data sets: a workgroup whose threads would get fewer than two cells each in the PG phase is halved (down to 256 threads) -- its head, its
+        // barriers and its reductions are paid per wave (fp64, 50 items: 1 000 subjects 37.2 -> 32.0 us per sweep, 10 000 subjects 42.8 -> 40.4)
+        if (cfg.block_threads == 0 && cfg.grid_blocks == 0) {
+            while (block_threads > 256) {
+                const int nw = block_threads / 64;
+                const int pc = sizeof(real) == 8 ? 1 : std::max(1, 16 / nw);
+                const int64_t g = std::max<int64_t>(1, std::min<int64_t>((N + nw - 1) / nw, (int64_t)cu_count * pc));
+                const int64_t rows = (N + g - 1) / g;
+                if (rows * J >= 2 * (int64_t)block_threads) break;
+                block_threads = std::max(256, block_threads / 2 / 64 * 64);
+            }
+        }
         const int nWaves = block_threads / 64;
         const int64_t need = (N + nWaves - 1) / nWaves;         // at least one subject per wave
         const int per_cu = sizeof(real) == 8 ? 1 : std::max(1, 16 / nWaves);       // resident workgroups per CU (the fp64 kernel's registers admit one)
@@ -367,10 +385,10 @@ template <typename real> struct Engine : EngineBase {
         for (int j = 0; j < J; ++j) { par[j] = 1.0; par[3 * J + j] = 1.0; }
         par[par_off_sigp(J) + 0] = 1.0; par[par_off_sigp(J) + 3] = 1.0;
         par[par_off_derived(J)] = (double)J;
-        for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpy(dParB[k].p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
+        for (int k = 0; k < 2; ++k) H2D(dParB[k].p, par.data(), par.size() * sizeof(double));
         if (dNu.p) {
             std::vector<real> ones(dNu.bytes / sizeof(real), real(1));
-            HIPCHK(hipMemcpy(dNu.p, ones.data(), dNu.bytes, hipMemcpyHostToDevice));
+            H2D(dNu.p, ones.data(), dNu.bytes);
         }
         timing.lanes_per_row = W; timing.block_threads = block_threads; timing.grid_blocks = grid_blocks;
         timing.lds_bytes = (int32_t)std::max(lds_pass[0], lds_pass[1]); timing.cu_count = cu_count;
@@ -747,9 +765,11 @@ template <typename real> struct Engine : EngineBase {
 
     int reset_trace() override {
         rows_done = 0; post_rows = 0;
-        HIPCHK(hipMemset(dSumTheta.p, 0, dSumTheta.bytes));
-        HIPCHK(hipMemset(dSumZeta.p, 0, dSumZeta.bytes));
-        if (dSumNu.p) HIPCHK(hipMemset(dSumNu.p, 0, dSumNu.bytes));
+        // on the engine's own stream: ordered after the run that filled the sums and before the next one (a NULL-stream fill is ordered with neither)
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipMemsetAsync(dSumTheta.p, 0, dSumTheta.bytes, stream));
+        HIPCHK(hipMemsetAsync(dSumZeta.p, 0, dSumZeta.bytes, stream));
+        if (dSumNu.p) HIPCHK(hipMemsetAsync(dSumNu.p, 0, dSumNu.bytes, stream));
         return 0;
     }
 
@@ -770,8 +790,8 @@ template <typename real> struct Engine : EngineBase {
         std::vector<double> g1((size_t)2 * J + PMAX * PMAX, 0.0);         // K0 | column sums of logT | x'x : summed over the devices
         DevBuf dYc, dLc, dStat, dFlag;
         if (int rc = dYc.alloc(NJ)) return rc;
-        HIPCHK(hipMemcpy(dYc.p, Y, NJ, hipMemcpyHostToDevice));
-        if (is_rt()) { if (int rc = dLc.alloc(NJ * sizeof(double))) return rc; HIPCHK(hipMemcpy(dLc.p, logT, NJ * sizeof(double), hipMemcpyHostToDevice)); }
+        H2D(dYc.p, Y, NJ);
+        if (is_rt()) { if (int rc = dLc.alloc(NJ * sizeof(double))) return rc; H2D(dLc.p, logT, NJ * sizeof(double)); }
         if (int rc = dStat.alloc((size_t)2 * J * sizeof(double))) return rc;
         if (int rc = dFlag.alloc(sizeof(unsigned int))) return rc;
         hipLaunchKernelGGL(colstats_cm_kernel, dim3(J), dim3(256), 0, stream, dYc.as<uint8_t>(), dLc.as<double>(), (long long)N, is_rt() ? 1 : 0, dStat.as<double>(), J, dFlag.as<unsigned int>());
@@ -804,7 +824,7 @@ template <typename real> struct Engine : EngineBase {
             const int NB = 256;
             if (int rc = dMean.alloc((size_t)J * sizeof(double))) return rc;
             if (int rc = dPart.alloc((size_t)NB * J * sizeof(double))) return rc;
-            HIPCHK(hipMemcpy(dMean.p, mean.data(), (size_t)J * sizeof(double), hipMemcpyHostToDevice));
+            H2D(dMean.p, mean.data(), (size_t)J * sizeof(double));
             hipLaunchKernelGGL((to_rows_kernel<double, real>), tgrid, dim3(256), 0, stream, dLc.as<double>(), (long long)N, J, dMean.as<double>(), dC.as<real>());
             hipLaunchKernelGGL((colsq_kernel<real>), dim3(NB), dim3(128), 0, stream, dC.as<real>(), (long long)N, J, dPart.as<double>());
             HIPCHK(hipGetLastError());
@@ -825,14 +845,14 @@ template <typename real> struct Engine : EngineBase {
             if (Fk > 0) {
                 DevBuf dXc;
                 if (int rc = dXc.alloc((size_t)N * Fk * sizeof(double))) return rc;
-                HIPCHK(hipMemcpy(dXc.p, X, (size_t)N * Fk * sizeof(double), hipMemcpyHostToDevice));
+                H2D(dXc.p, X, (size_t)N * Fk * sizeof(double));
                 hipLaunchKernelGGL((to_rows_kernel<double, real>), dim3((unsigned)((N + 31) / 32), (unsigned)((Fk + 31) / 32)), dim3(256), 0, stream, dXc.as<double>(), (long long)N, Fk,
                                    (const double*)nullptr, dX.as<real>());
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipStreamSynchronize(stream));
             }
         }
-        HIPCHK(hipMemcpy(dCst.p, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
+        H2D(dCst.p, cst.data(), cst.size() * sizeof(double));
         has_data = true;
         stats_valid = false;
         return 0;
@@ -899,7 +919,7 @@ template <typename real> struct Engine : EngineBase {
         }
         DevBuf dT;
         if (int rc = dT.alloc(tv.size() * sizeof(double))) return rc;
-        HIPCHK(hipMemcpy(dT.p, tv.data(), tv.size() * sizeof(double), hipMemcpyHostToDevice));
+        H2D(dT.p, tv.data(), tv.size() * sizeof(double));
         if (!dTruthTheta.p) { if (int rc = dTruthTheta.alloc((size_t)N * sizeof(double))) return rc; if (int rc = dTruthZeta.alloc((size_t)N * sizeof(double))) return rc; }
         GenArgs g{};
         g.Y = dY.as<uint8_t>(); g.C = dC.p; g.X = dX.p; g.theta = dTruthTheta.as<double>(); g.zeta = dTruthZeta.as<double>();
@@ -926,7 +946,7 @@ template <typename real> struct Engine : EngineBase {
         if (is_rt()) {
             if (int rc = dMean.alloc((size_t)J * sizeof(double))) return rc;
             if (int rc = dPart2.alloc((size_t)NB * J * sizeof(double))) return rc;
-            HIPCHK(hipMemcpy(dMean.p, col_mean.data(), (size_t)J * sizeof(double), hipMemcpyHostToDevice));
+            H2D(dMean.p, col_mean.data(), (size_t)J * sizeof(double));
             hipLaunchKernelGGL((center_kernel<real>), dim3(NB), dim3(128), 0, stream, dC.as<real>(), (long long)N, J, dMean.as<double>(), dPart2.as<double>());
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(stream));
@@ -939,7 +959,7 @@ template <typename real> struct Engine : EngineBase {
             for (int j = 0; j < J; ++j) { const double dm = col_mean[j] - mu; ss += cst[cst_off_csq(J) + j] + (double)N * dm * dm; }
             cst[cst_off_mu(J)] = mu; cst[cst_off_mu(J) + 1] = std::sqrt(ss / ((double)N * J - 1.0));
         }
-        HIPCHK(hipMemcpy(dCst.p, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
+        H2D(dCst.p, cst.data(), cst.size() * sizeof(double));
         has_data = true;
         stats_valid = false;
         return 0;
@@ -983,7 +1003,7 @@ template <typename real> struct Engine : EngineBase {
     int up_real(DevBuf& d, const double* src, size_t n) {
         std::vector<real> t(n);
         for (size_t k = 0; k < n; ++k) t[k] = (real)src[k];
-        HIPCHK(hipMemcpy(d.p, t.data(), n * sizeof(real), hipMemcpyHostToDevice));
+        H2D(d.p, t.data(), n * sizeof(real));
         return 0;
     }
     int down_real(const DevBuf& d, double* dst, size_t n) {
@@ -1014,7 +1034,7 @@ template <typename real> struct Engine : EngineBase {
             else if (cfg.model != ERM_MODEL_NULL) for (int u = 0; u < nbeta(); ++u) b[u] = st->beta[u];
         }
         { double t = 0.0; for (int j = 0; j < J; ++j) t += 1.0 / par[3 * J + j]; par[par_off_derived(J)] = t; }
-        HIPCHK(hipMemcpy(dParB[cur].p, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
+        H2D(dParB[cur].p, par.data(), par.size() * sizeof(double));
         if (st->theta) if (int rc = up_real(dTheta, st->theta, N)) return rc;
         if (st->zeta) if (int rc = up_real(dZeta, st->zeta, N)) return rc;
         if (st->nu && dNu.p) {
@@ -1026,7 +1046,7 @@ template <typename real> struct Engine : EngineBase {
                     if (!(v > 0.0)) return fail(ERM_ERR_ARG, "nu must be positive");   // @assert src/Draw.pl.jl:477
                     t[(size_t)i * J + j] = (real)v;
                 }
-                HIPCHK(hipMemcpy(dNu.p, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
+                H2D(dNu.p, t.data(), t.size() * sizeof(real));
             }
         }
         return 0;
@@ -1527,8 +1547,8 @@ int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32
     HIPCHK(hipSetDevice(device));
     DevBuf d0, d1, dout;
     if (int rc = dout.alloc(n * sizeof(double))) return rc;
-    if (par0) { if (int rc = d0.alloc(n * sizeof(double))) return rc; HIPCHK(hipMemcpy(d0.p, par0, n * sizeof(double), hipMemcpyHostToDevice)); }
-    if (par1) { if (int rc = d1.alloc(n * sizeof(double))) return rc; HIPCHK(hipMemcpy(d1.p, par1, n * sizeof(double), hipMemcpyHostToDevice)); }
+    if (par0) { if (int rc = d0.alloc(n * sizeof(double))) return rc; H2D(d0.p, par0, n * sizeof(double)); }
+    if (par1) { if (int rc = d1.alloc(n * sizeof(double))) return rc; H2D(d1.p, par1, n * sizeof(double)); }
     const int bt = 256; const int gb = (int)((n + bt - 1) / bt);
     if (precision == ERM_PREC_F32)
         hipLaunchKernelGGL((sample_batch_kernel<float>), dim3(gb), dim3(bt), 0, 0, which, seed, site, sweep, (long long)n, d0.as<double>(), d1.as<double>(), dout.as<double>());

@@ -83,3 +83,24 @@ def test_farm_through_the_sample_mirror_and_errors():
         f.run(1)                                   # no data yet: the chain's own error, named
     with pytest.raises(L.ErmError, match="no post-burn-in"):
         f.get_mean()
+
+
+def test_farm_runs_are_reproducible():
+    """Twenty farms in a row (three host threads inside erm_set_data / erm_run each time) give chain 0 the same trace: a fill or an upload on the NULL
+    stream that is not complete when an engine's own non-blocking stream starts working shows up here (it did, about once in 500 farm runs)."""
+    L = pu.ge.load_package()._lib
+    N, J, T, nch = 600, 8, 6, 3
+    Y, logT, X, init, _ = pu.make_problem("rtirt", N, J)
+    st = {("lambda_" if k == "lam" else k): v for k, v in init.items()}
+    ref = None
+    for _ in range(20):
+        farm = L.Farm([0] * nch, model=pu.MODELS["rtirt"], n_item=J, n_subj=N, n_feat=X.shape[1], n_iter=T, n_chain=1, n_burnin=T // 2, cov2one=1, q_rt=0.85,
+                      seed=1234, precision=1, trace_mode=1)
+        farm.set_data(Y, logT, X)
+        for l in range(nch):
+            farm.set_state(l, **st)
+        farm.run(T)
+        tr = farm.trace(L.TRACE_RA).copy()
+        if ref is None:
+            ref = tr
+        assert np.array_equal(tr, ref)
