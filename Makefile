@@ -5,7 +5,7 @@ LIB := $(PKG)/libertirt.so
 
 all: $(LIB) tools/erm_cli oracle/liberm_oracle.so
 
-$(LIB): $(PKG)/csrc/ertirt.hip $(PKG)/csrc/erm_kernels.hpp $(PKG)/csrc/erm_rng.hpp include/ertirt.h
+$(LIB): $(PKG)/csrc/ertirt.hip $(PKG)/csrc/erm_kernels.hpp $(PKG)/csrc/erm_rng.hpp $(PKG)/csrc/erm_layout.hpp $(PKG)/csrc/erm_geometry.hpp include/ertirt.h
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I include $(PKG)/csrc/ertirt.hip -o $@ $(ERM_HIPCC_FLAGS)
 
 tools/erm_cli: tools/erm_cli.c include/ertirt.h $(LIB)

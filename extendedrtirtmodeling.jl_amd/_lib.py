@@ -24,7 +24,7 @@ EXPORTS = [
     "erm_post_count", "erm_get_diagnostics", "erm_simulate_data", "erm_get_truth", "erm_get_data", "erm_get_timing", "erm_last_error", "erm_version", "erm_debug_sample", "erm_sample_gig",
     "erm_set_shard", "erm_copy", "erm_rccl_unique_id", "erm_set_shard_rccl",
     "erm_farm_create", "erm_farm_destroy", "erm_farm_chains", "erm_farm_engine", "erm_farm_set_data", "erm_farm_set_state", "erm_farm_get_state",
-    "erm_farm_run", "erm_farm_reset_trace", "erm_farm_get_trace", "erm_farm_get_mean", "erm_farm_post_count", "erm_farm_used_rccl",
+    "erm_farm_run", "erm_farm_reset_trace", "erm_farm_get_trace", "erm_farm_get_mean", "erm_farm_post_count", "erm_farm_used_rccl", "erm_farm_get_timing",
 ]
 
 
@@ -39,8 +39,15 @@ class erm_config(C.Structure):
         ("cov2one", C.c_int32), ("sigp_mode", C.c_int32), ("chain_id", C.c_int32), ("q_rt", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int32), ("precision", C.c_int32), ("trace_mode", C.c_int32),
         ("lanes_per_row", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32), ("profile", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32), ("nu_trace_max_gb", C.c_double),
     ]
+
+
+FLAG_NO_FUSE, FLAG_NO_GRAPH, FLAG_FARM_FORCE_RCCL = 1, 2, 4
+
+
+class erm_farm_timing(C.Structure):
+    _fields_ = [("run_wall_ms", C.c_double), ("gather_ms", C.c_double), ("allreduce_ms", C.c_double), ("rccl_ranks", C.c_int32), ("n_devices", C.c_int32)]
 
 
 _DP = C.POINTER(C.c_double)
@@ -123,6 +130,7 @@ def load():
     lib.erm_farm_post_count.argtypes = [H]
     lib.erm_farm_post_count.restype = C.c_int64
     lib.erm_farm_used_rccl.argtypes = [H]
+    lib.erm_farm_get_timing.argtypes = [H, C.POINTER(erm_farm_timing), C.c_void_p]
     _lib = lib
     return lib
 
@@ -391,6 +399,15 @@ class Farm:
         st, keep = state_struct(bufs)
         check(self._lib.erm_farm_get_mean(self._h, C.byref(st)))
         return bufs
+
+    def timing(self):
+        """erm_farm_get_timing: wall-clock of the last run / gather, per-chain device time, ranks of the library's RCCL communicator."""
+        t = erm_farm_timing()
+        run_ms = np.zeros(self.n_chains, dtype=np.float64)
+        check(self._lib.erm_farm_get_timing(self._h, C.byref(t), run_ms.ctypes.data))
+        out = {f: getattr(t, f) for f, _ in erm_farm_timing._fields_}
+        out["run_ms"] = run_ms
+        return out
 
     def item_trace(self):
         """Item-level trace rows in the single-engine order (row m * nChain + l = iteration m of chain l)."""

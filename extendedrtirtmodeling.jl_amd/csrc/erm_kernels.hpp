@@ -15,21 +15,10 @@
 // HBM layout: Y u8 [N][J], centred logT / omega / nu `real` [N][J] (row-major), theta/zeta `real` [N].
 #pragma once
 #include <type_traits>
+#include "erm_layout.hpp"
 #include "erm_rng.hpp"
 
 namespace erm {
-
-enum Model : int { MLIRT = 0, RTIRT = 1, CROSSQR = 2, LATENTQR = 3, NULLM = 4, CROSS = 5, LATENT = 6 };
-// Model families.  The non-quantile variants (GibbsRtIrtNull / Cross / Latent, src/GibbsRtIrt.pl.jl:367-426,
-// src/GibbsRtIrtCross.pl.jl:176-235, src/GibbsRtIrtLatent.pl.jl:168-233) run their quantile sibling's kernels with nu == 1, k1 = 0,
-// k2 = 1 (the host passes those; x*1, x/1 and x+0 are exact) and without any nu traffic; the draws that differ are spelled out.
-__host__ __device__ constexpr bool fam_rt(int M) { return M == RTIRT || M == NULLM; }       // bivariate (theta, zeta) structure, one pass
-__host__ __device__ constexpr bool fam_lq(int M) { return M == LATENTQR || M == LATENT; }   // zeta regressed on [1 X theta], one pass
-__host__ __device__ constexpr bool fam_cq(int M) { return M == CROSSQR || M == CROSS; }     // cross-relation rho, two passes
-__host__ __device__ constexpr bool has_nu(int M) { return M == CROSSQR || M == LATENTQR; }
-
-constexpr int PMAX = 16;            // max columns of the latent-regression design ([1 X theta])
-constexpr int NITEMARR = 8;         // per-item arrays staged in LDS
 
 struct Ctl {
     uint32_t sweep;       // global index of the sweep whose item draws are current
@@ -39,37 +28,11 @@ struct Ctl {
     unsigned long long dbg_attempts, dbg_trips, dbg_cells;   // -DERM_DIAG_BUILD with ERM_PASS_STOP=9: PG attempts, wave trips, cells
 };
 
-// parameter block written by the tiny step (fp64): a, b, lambda, sig2t, rho : 5 x J, then Sigp(4), beta(2*PMAX),
-// then derived scalars: [0] sum_j 1/sig2t_j
-__host__ __device__ inline int par_off_sigp(int J) { return 5 * J; }
-__host__ __device__ inline int par_off_beta(int J) { return 5 * J + 4; }
-__host__ __device__ inline int par_off_derived(int J) { return 5 * J + 4 + 2 * PMAX; }
-__host__ __device__ inline int par_size(int J) { return 5 * J + 4 + 2 * PMAX + 4; }
-
-// data constants (fp64): K0[J], m[J] (column means of logT), csq[J] (sum of squared centred logT), muLam, sdLam,
-// XtX[PMAX*PMAX] = x'x with x = [1 X] (iteration-invariant, src/Draw.pl.jl:383-386 recomputes it every sweep), XtXinv[PMAX*PMAX]
-__host__ __device__ inline int cst_off_k0(int) { return 0; }
-__host__ __device__ inline int cst_off_m(int J) { return J; }
-__host__ __device__ inline int cst_off_csq(int J) { return 2 * J; }
-__host__ __device__ inline int cst_off_mu(int J) { return 3 * J; }
-__host__ __device__ inline int cst_off_xtx(int J) { return 3 * J + 2; }
-__host__ __device__ inline int cst_off_xinv(int J) { return 3 * J + 2 + PMAX * PMAX; }
-__host__ __device__ inline int cst_size(int J) { return 3 * J + 2 + 2 * PMAX * PMAX; }
-
-// statistics layout of one slab row: NSTAT item statistics x J, then NG globals
-//   MlIrt        : S0 S1 S2 K1             | x'theta, LL
-//   RtIrt family : S0 S1 S2 K1 G           | x'theta, x'zeta, tt, tz, zz, LL
-//   Latent family: S0 S1 S2 K1 G           | x'theta, tt, x'u, tu, uu, snu, snu2, sz, zz, LL      (u = zeta - k1 nu)
-//   Cross family : S0 S1 S2 K1 W0 W1 W2 V  | LL_A        (pass A)       R0 R1 | zz, LL_B   (pass B)
-template <int MODEL, int PHASE> struct Stats {
-    static constexpr int NSTAT = (MODEL == MLIRT) ? 4 : (fam_cq(MODEL) ? (PHASE == 0 ? 8 : 2) : 5);
-    __host__ __device__ static int ng(int p) { return (MODEL == MLIRT) ? p + 1 : fam_rt(MODEL) ? 2 * p + 4 : fam_lq(MODEL) ? 2 * p + 8 : (PHASE == 0 ? 1 : 2); }
-};
-
 template <typename real> struct PassArgs {
     const uint8_t* Y; const real* C; real* omega; real* nu; const real* X;
     real* theta; real* zeta;
     const double* par; const double* cst; double* slab; const Ctl* ctl;
+    const double* pgtab;                            // [PG_NBIN][4] proposal table of the Polya-Gamma sampler (erm_rng.hpp, pg_bin)
     double* gslab; unsigned int* gcnt;              // per-group reduced slabs and arrival counters (GROUP consecutive workgroups)
     double* sum_theta; double* sum_zeta; double* sum_nu;
     real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] (CrossQr's tr_nu: [rows][N][J]) or nullptr
@@ -82,8 +45,7 @@ template <typename real> struct PassArgs {
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // -DERM_DIAG_BUILD only: skip everything after stage k (0 = run everything); ignored by the shipped library
     unsigned long long* dbg_ts;   // diagnostics only (ERM_TIMELINE): [2 workgroups][16 waves][16 checkpoints] of the 100 MHz wall clock
-    int acc_off;          // byte offset in dynamic LDS of the per-wave item accumulators [nWaves][NSTAT][J], the LAST region of a launch's LDS; the
-                          // fp64 engine's PG-phase value queues ([nWaves][4][128] x 8 bytes) are overlaid on it
+    int acc_off;          // byte offset in dynamic LDS of the per-wave item accumulators [nWaves][NSTAT][J], the LAST region of a launch's LDS
     uint32_t row_base;    // subject index of local row 0 in the whole data set (subject-sharded chains; 0 otherwise): the random streams are
                           // addressed by the GLOBAL subject index, so a chain does not depend on how its subjects are spread over devices
 };
@@ -113,16 +75,7 @@ template <typename T> __device__ __forceinline__ T bfly_sum(T v, int lo, int hi)
 __device__ __forceinline__ float  log1pexp_r(float x)  { return fmaxf(x, 0.f) + r_log(1.f + r_exp(-fabsf(x))); }
 __device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
-#ifndef ERM_F32_THREADS
-#define ERM_F32_THREADS 1024     // threads per workgroup of the fp32 engine = the register budget the row-pass kernel is compiled for (128 VGPRs)
-#endif
-#ifndef ERM_F64_THREADS
-#define ERM_F64_THREADS 1024     // fp64 engine: 16 waves per CU (4 per SIMD), 128 VGPRs each -- ONE workgroup per CU, like the fp32 engine.  A/B on one box against 768
-#endif                           // threads (168 VGPRs, no spills): RtIrt 111.6 -> 106.7 us, MlIrt 98.2 -> 92.8, 500 000 x 100 922 -> 883; the 13-18 spilled registers
-                                 // are loop-invariant fp64 constants re-read by one queue evaluation.  LatentQr (72 spills at 128 VGPRs: 103.6 -> 113.0 us) stays at 768.
-#define ERM_F64_THREADS_LATENTQR 768
 constexpr double LOG_2PI = 1.8378770664093454836;
-constexpr int GROUP = 16;  // workgroups whose slab rows are summed by the last of them to finish
 constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
 
 // Stage-timing / counting diagnostics (early returns that leave GARBAGE results, PG attempt counters) exist only in a library built with
@@ -238,8 +191,6 @@ __device__ inline double beta_normal(uint64_t seed, uint32_t chain, uint32_t swe
     return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
 
-constexpr int TINY_THREADS = 1024;
-constexpr int TINY_WORK = 2 * (2 * PMAX) * (2 * PMAX) + 12 * PMAX + 16;   // LDS scratch doubles for the structural wave
 
 // One tiny step = tiny_items (every thread of the workgroup; no barrier inside), a workgroup barrier, tiny_struct (ONE wave; only
 // wave-level synchronisation inside).  Both work on an LDS-resident parameter block `par` (read: the previous values, written in
@@ -648,7 +599,7 @@ __device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* pa
 // (T.par_out, T.ctl_out, traces).  Inputs and outputs are distinct (double-buffered) allocations, so a workgroup that starts late
 // never sees a half-updated block.  That removes one kernel boundary and the tiny kernel's cold start from every sweep.
 template <int MODEL, typename real, int PHASE, bool FUSED>
-__global__ void __launch_bounds__(sizeof(real) == 8 ? (MODEL == LATENTQR ? ERM_F64_THREADS_LATENTQR : ERM_F64_THREADS) : ERM_F32_THREADS) pass_kernel(PassArgs<real> A, TinyArgs T)
+__global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) pass_kernel(PassArgs<real> A, TinyArgs T)
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
@@ -665,8 +616,7 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? (MODEL == LATENTQR ? ERM_F
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* sh_struct = reinterpret_cast<double*>(smem);        // 8 + 2*PMAX doubles
-    // the per-wave item accumulators close the launch's dynamic LDS (A.acc_off): they are first written in the column phase, so the fp64
-    // engine's PG-phase value queues (dead by then) share that space and only their excess over it is extra LDS
+    // the per-wave item accumulators close the launch's dynamic LDS (A.acc_off)
     double* sh_acc = reinterpret_cast<double*>(smem + A.acc_off);    // [nWaves][NSTAT][J]
     double* sh_gacc = sh_struct + 8 + 2 * PMAX;                 // [nWaves][NG]
     real* sh_item = reinterpret_cast<real*>(sh_gacc + (size_t)nWaves * NG);    // [NITEMARR][J]
@@ -694,6 +644,23 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? (MODEL == LATENTQR ? ERM_F
         __shared__ double2 sh_logtab[128];
         fm::fill_log_table(sh_logtab, (int)threadIdx.x, (int)blockDim.x);
         logtab = sh_logtab;
+    }
+    // the Polya-Gamma proposal table: {lam, 1/lam, M, q} per z-bin rounded to fp32 (decisions), 1/lam in fp64 (the fp64 engine's values);
+    // published by the same barrier (pass_static_lds() in erm_layout.hpp counts these arrays)
+    [[maybe_unused]] const float4* sh_pgf = nullptr;
+    [[maybe_unused]] const double* sh_pgc = nullptr;
+    if constexpr (PHASE == 0) {
+        __shared__ float4 sh_pgf_[PG_NBIN];
+        for (int k = threadIdx.x; k < PG_NBIN; k += blockDim.x) {
+            const double* b = A.pgtab + 4 * k;
+            sh_pgf_[k] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+        }
+        sh_pgf = sh_pgf_;
+        if constexpr (sizeof(real) == 8) {
+            __shared__ double sh_pgc_[PG_NBIN];
+            for (int k = threadIdx.x; k < PG_NBIN; k += blockDim.x) sh_pgc_[k] = A.pgtab[4 * k + 1];
+            sh_pgc = sh_pgc_;
+        }
     }
     const uint8_t* __restrict__ gY = A.Y;
     const real* __restrict__ gC = A.C;
@@ -1069,82 +1036,18 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? (MODEL == LATENTQR ? ERM_F
         uint32_t att = 0;
         real th = active ? theta_of(rr) : real(0);
         real z = active ? real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])) : real(0);
+        int kb = pg_bin_index(z);                     // the cell's row of the proposal table
         real* om = A.omega + (size_t)qrow0 * J;
         const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
         [[maybe_unused]] unsigned int n_att = 0, n_trip = 0;
         // (letting a wave whose queue ran dry serve other waves' queues was tried: the hardware favours a SIMD's oldest wave, so the
         // four waves of a SIMD finish up to 17 us apart -- but the phase is VALU-throughput-bound, the SIMD is busy until the last
         // one ends either way, and the stealing logic only added instructions: 78.5 vs 75.3 us per sweep)
-        if constexpr (sizeof(real) == 8) {
-            // fp64 engine.  An attempt is DECIDED in fp32 behind guard bands (pg1_filter); the fp64 value of an accepted draw costs 30-70
-            // fp64 instructions that differ by piece of the envelope (tail: log + division; left: one of AS 241's rationals; z >= 1/t: the
-            // inverse-Gaussian root).  Evaluated inside the attempt loop every wave would run every piece on every trip with a fraction of
-            // its lanes.  Instead an accepted lane files (cell, word 1) in a wave-private LDS queue of its piece and moves on; whenever a
-            // queue holds 64 entries the whole wave evaluates that ONE piece for 64 cells, every lane busy, and stores the omegas.
-            // Positions come from ballots (wave-synchronous: no atomics); the value depends only on (cell, word 1), never on the lane.
-            constexpr int QCAP = 128;                                // a queue holds < 64 entries before a push of <= 64
-            uint2* pq = reinterpret_cast<uint2*>(smem + A.acc_off) + (size_t)wave * 4 * QCAP;
-            int qhd[4] = {0, 0, 0, 0}, qn[4] = {0, 0, 0, 0};         // wave-uniform: first entry and number of entries per piece
-            auto flush = [&](int T, int n) {                         // evaluate and store the first n (<= 64) entries of queue T
-                wave_sync();
-                const bool on = lane < n;
-                const uint2 e = pq[T * QCAP + ((qhd[T] + (on ? lane : 0)) & (QCAP - 1))];
-                const int cc = (int)(e.x & 0x7FFFFFFFu);
-                double x;
-                if (T == 1) x = pg1_value_central(e.y);             // small-z left pieces do not depend on z at all
-                else if (T == 2) x = pg1_value_mid(e.y, logtab);
-                else {
-                    int r2, j2;
-                    locate(cc, r2, j2);
-                    const double zz = 0.5 * fabs((double)sh_a[j2] * ((double)theta_of(r2) - (double)sh_b[j2]));
-                    if (T == 0) x = pg1_value_tail(zz, e.y, logtab);
-                    else x = pg1_value_large(zz >= 1.5625 ? zz : 2.0, e.y, (e.x >> 31) != 0u);
-                }
-                if (on) om[cc] = (real)(0.25 * x);
-                qhd[T] += n; qn[T] -= n;
-            };
-            while (__any(active)) {
-#ifdef ERM_DIAG_BUILD
-    #ifdef ERM_DIAG_BUILD
-            ++n_trip; n_att += active ? 1u : 0u;
-#endif
-#endif
-                int piece = PG_NONE;
-                uint2 ent = make_uint2(0u, 0u);
-                if (active) {
-                    uint32_t w0, w1, w2, w3;
-                    philox4x32_10((uint32_t)(qrow0 + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
-                    const PgDecision d = pg1_filter((double)z, w0, w1, w2, w3);
-                    bool acc_ = d.accept;
-                    if (__any(d.unsure)) {                           // inside a guard band: the reference form decides, and its value is stored at once
-                        double o2;
-                        const bool a2 = pg1_attempt_ref_call((double)z, w0, w1, w2, w3, &o2);
-                        if (d.unsure) { acc_ = a2; if (a2) om[c] = (real)o2; }
-                    }
-                    const bool give_up = att + 1u >= (uint32_t)MAX_TRIES;
-                    if (acc_ || give_up) {
-                        if (acc_ && !d.unsure) { piece = d.piece; ent = make_uint2((uint32_t)c | (d.second ? 0x80000000u : 0u), w1); }
-                        else if (!acc_) om[c] = (real)(0.25 * (double)d.x);
-                        c = (int)atomicAdd(qhead, 1u);
-                        att = 0;
-                        active = c < ncell;
-                        if (active) { locate(c, rr, j); th = theta_of(rr); z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
-                    } else ++att;
-                }
-#pragma unroll
-                for (int T = 0; T < 4; ++T) {
-                    const unsigned long long m = __ballot(piece == T + 1);
-                    if (m != 0ull) {
-                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (piece == T + 1) pq[T * QCAP + ((qhd[T] + qn[T] + pos) & (QCAP - 1))] = ent;
-                        qn[T] += __popcll(m);
-                        if (qn[T] >= 64) flush(T, 64);
-                    }
-                }
-            }
-#pragma unroll
-            for (int T = 0; T < 4; ++T) { if (qn[T] > 0) flush(T, qn[T]); }
-        } else {
+        // Both engines run the same flat loop.  fp64: the attempt is DECIDED in fp32 behind guard bands and its value -- the fp64 logarithm
+        // of u1 and one reciprocal, whichever piece proposed -- is evaluated in the same trip for every lane (pg1_attempt_f64); the rare lane
+        // inside a guard band, or with z >= 8, repeats the attempt through the reference form (a real call).  Round 2's proposal by the
+        // inverse normal cdf needed a different 30-70-instruction fp64 evaluation per quantile range and therefore per-wave value queues
+        // sorted by piece (four ballot rounds per trip, 64 KB of LDS, scattered 8-byte stores); this form needs none of it.
         while (__any(active)) {
 #ifdef ERM_DIAG_BUILD
             ++n_trip; n_att += active ? 1u : 0u;
@@ -1153,16 +1056,22 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? (MODEL == LATENTQR ? ERM_F
                 uint32_t w0, w1, w2, w3;
                 philox4x32_10((uint32_t)(qrow0 + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
                 real w;
-                const bool acc_ = pg1_attempt(z, w0, w1, w2, w3, w);
+                bool acc_, unsure;
+                if constexpr (sizeof(real) == 8) acc_ = pg1_attempt_f64<true>(z, w0, w1, w2, w3, sh_pgf[kb], sh_pgc[kb], logtab, w, unsure);
+                else { acc_ = pg1_attempt(z, w0, w1, w2, w3, sh_pgf[kb], w); unsure = !(z < (real)PG_ZMAX); }
+                if (__any(unsure)) {                             // inside a guard band / z >= 8: the reference form decides
+                    double o2;
+                    const bool a2 = pg1_attempt_ref_call((double)z, w0, w1, w2, w3, A.pgtab, &o2);
+                    if (unsure) { acc_ = a2; w = (real)o2; }
+                }
                 if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
                     om[c] = w;
                     c = (int)atomicAdd(qhead, 1u);
                     att = 0;
                     active = c < ncell;
-                    if (active) { locate(c, rr, j); th = theta_of(rr); z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); }
+                    if (active) { locate(c, rr, j); th = theta_of(rr); z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); kb = pg_bin_index(z); }
                 } else ++att;
             }
-        }
         }
         if (ERM_DIAG_ON(A, 9)) {
             Ctl* cw = const_cast<Ctl*>(A.ctl);
@@ -1461,7 +1370,6 @@ __global__ void __launch_bounds__(sizeof(real) == 8 ? (MODEL == LATENTQR ? ERM_F
     stamp(13);
 }
 
-constexpr int tiny_lds_doubles(int NS0, int NS1, int J) { return NS0 + NS1 + J + TINY_WORK + 2 * PMAX * PMAX + par_size(J); }
 
 template <int MODEL, int STEP>
 __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
@@ -1762,7 +1670,7 @@ __global__ void center_kernel(real* C, long long N, int J, const double* mean, d
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename real>
 __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uint32_t sweep, long long n,
-                                    const double* par0, const double* par1, double* out)
+                                    const double* par0, const double* par1, double* out, const double* pgtab)
 {
     __shared__ double2 sh_logtab[128];
     fm::fill_log_table(sh_logtab, (int)threadIdx.x, (int)blockDim.x);
@@ -1777,25 +1685,25 @@ __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uin
     case 0: v = (double)uniform<real>(st); break;
     case 1: v = (double)normal<real>(st); break;
     case 2: v = (double)expo<real>(st); break;
-    case 3: v = (double)pg1<real>(st, (real)par0[k]); break;
+    case 3: v = (double)pg1<real>(st, (real)par0[k], pgtab); break;
     case 4: v = (double)invgauss(st, (real)par0[k], (real)par1[k]); break;
     case 5: v = truncnorm0(st, par0[k], par1[k]); break;
     case 6: v = gamma_mt(st, par0[k]); break;
-    case 7: { const real z = (real)par0[k]; v = (double)pg_tail_weight<real>(z, real(0.125) * Const<real>::PI * Const<real>::PI + real(0.5) * z * z); } break;
+    case 7: v = pg_tail_weight(par0[k], pgtab); break;
     case 8: v = (double)qr_weight<real>(st, (real)par0[k], (real)par1[k]); break;
     case 9: v = (double)ndtri((real)par0[k]); break;
     case 11: v = fm::log(par0[k]); break;           // the cell path's fp64 elementary functions (erm_rng.hpp, namespace fm)
     case 12: v = fm::exp_neg(par0[k]); break;
     case 13: v = fm::sqrt(par0[k]); break;
     case 14: v = fm::div(par0[k], par1[k]); break;
-    case 10: {     // PG(1, par0) through the reference form of the attempt (every decision in `real` arithmetic)
-        const real z = real(0.5) * r_abs((real)par0[k]);
-        real o = real(0);
+    case 10: {     // PG(1, par0) through the reference form of the attempt (every statement in fp64)
+        const double z = 0.5 * fabs(par0[k]);
+        double o = 0.0;
         for (int tries = 0; tries < MAX_TRIES; ++tries) {
             const uint32_t w0 = st.next(), w1 = st.next(), w2 = st.next(), w3 = st.next();
-            if (pg1_attempt_ref<real>(z, w0, w1, w2, w3, o)) break;
+            if (pg1_attempt_ref(z, w0, w1, w2, w3, pgtab, o)) break;
         }
-        v = (double)o;
+        v = o;
     } break;
     }
     out[k] = v;

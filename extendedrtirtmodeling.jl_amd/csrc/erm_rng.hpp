@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "erm_layout.hpp"
 
 namespace erm {
 
@@ -317,7 +318,6 @@ __device__ __forceinline__ void far(double r, double& n, double& d)          // 
     n = fma(n, r, 5.46378491116411436990e+0); d = fma(d, r, 5.99832206555887937690e-1);
     n = fma(n, r, 6.65790464350110377720e+0); d = fma(d, r, 1.0);
 }
-__device__ __attribute__((noinline)) void far_fix(double r, double& n, double& d) { double n2, d2; far(r, n2, d2); if (r > 5.0) { n = n2; d = d2; } }
 __device__ __forceinline__ double central(double r) { double n, d; central(r, n, d); return n / d; }
 __device__ __forceinline__ double mid(double r) { double n, d; mid(r, n, d); return n / d; }
 __device__ __forceinline__ double far(double r) { double n, d; far(r, n, d); return n / d; }
@@ -338,282 +338,192 @@ template <> __device__ __forceinline__ float word_to_unif<float>(uint32_t w) { r
 
 // ---- Polya-Gamma PG(1, c) -------------------------------------------------------------------
 // Single-level rejection sampler for J*(1, z): one attempt = one Philox block (u0..u3), no inner loop.  Envelope pieces:
-//   x > t           : (pi/2) e^{-K x}, K = pi^2/8 + z^2/2, mass p = pi/(2K) e^{-K t}
-//   x <= t, z < 1/t : the Levy kernel a_0(x), mass q0 = 4 Phi(-1/sqrt t); acceptance factor e^{-z^2 x/2}
-//   x <= t, z >= 1/t: the IG(1/z,1) kernel on all x > 0, mass 2 e^{-z}; draws with x > t rejected
+//   x > t          : (pi/2) e^{-K x}, K = pi^2/8 + z^2/2, mass p = pi/(2K) e^{-K t};  X = t + E/K,  E = -log u1
+//   x <= t, z < 8  : in Z = x^{-1/2} >= a = 1/sqrt(t) the piece is 4 phi(Z) e^{-z^2/(2 Z^2)}; Robert's exponential proposal for a normal tail,
+//                    tilted per z:  Z = a + E/lam, kept with probability e^{g(Z) - M}, g(Z) = -(Z - lam)^2/2 - z^2/(2 Z^2), M >= max g;
+//                    envelope mass q = 4/(lam sqrt(2 pi)) e^{lam^2/2 - lam a + M}.  (lam, 1/lam, M, q) come from a table over z-bins of width
+//                    1/16 (pg_bin: Z*^2 = sqrt(10.6 + 1.07 z_k^2) for the bin's lower edge z_k, lam = Z* - z_k^2/Z*^3, M = g(Z*; z_k)).
+//   x <= t, z >= 8 : the IG(1/z,1) kernel on all x > 0, mass 2 e^{-z}; draws with x > t rejected (|eta| >= 16: the reference form only)
 // followed by the alternating-series test in ratio form (rho_n = a_n/a_0).  Specification shared with oracle/orc_rng.h.
-template <typename real> __device__ __forceinline__ real pg_tail_weight(real z, real K)
+// ONE logarithm of u1 serves both pieces of the common case and the value of an accepted draw is that logarithm and one reciprocal,
+// whatever the piece: no normal quantile, no piece-specific fp64 evaluation, nothing to sort by piece.  (Round 2 proposed the left
+// piece by the inverse normal cdf: 0.999 instead of 0.95 acceptance at z = 0, but three quantile ranges whose fp64 values had to be queued
+// by piece -- 648 VALU instructions per cell-update against DESIGN.md 4b's figure for this form.)
+constexpr double PG_ZMAX = 8.0;
+
+// the table entry of z-bin k: {lam, c = 1/lam, M, q}.  Host and device (the engine uploads the host's copy: one table per engine)
+__host__ __device__ inline void pg_bin(int k, double* out4)
 {
-    const real t = real(0.64);
-    const real p = r_div(Const<real>::PI, real(2) * K) * r_exp(-K * t);
-    const real qenv = (z < real(1.5625)) ? real(0.42259909466742100) : real(2) * r_exp(-z);
-    return r_div(p, p + qenv);
+    const double zk = (double)k / 16.0;
+    const double Zs2 = ::sqrt(10.6 + 1.07 * zk * zk), Zs = ::sqrt(Zs2);
+    const double d = zk * zk / (Zs * Zs2);
+    const double l = Zs - d, m = -0.5 * d * d - 0.5 * zk * zk / Zs2;
+    out4[0] = l; out4[1] = 1.0 / l; out4[2] = m;
+    out4[3] = 4.0 / (l * ::sqrt(2.0 * 3.14159265358979323846)) * ::exp(0.5 * l * l - 1.25 * l + m);
+}
+__device__ __forceinline__ int pg_bin_index(double z) { return (int)fmin(z * 16.0, (double)(PG_NBIN - 1)); }       // NaN -> the last bin (unused: z >= 8 takes the reference form)
+__device__ __forceinline__ int pg_bin_index(float z) { return (int)fminf(z * 16.0f, (float)(PG_NBIN - 1)); }
+
+// probability that an attempt proposes from the exponential tail (debug sampler 7); gtab: the [PG_NBIN][4] table in global memory
+__device__ __forceinline__ double pg_tail_weight(double z, const double* gtab)
+{
+    const double PId = 3.14159265358979323846;
+    const double K = 0.125 * PId * PId + 0.5 * z * z;
+    const double p = PId / (2.0 * K) * exp(-K * 0.64);
+    const double q = z < PG_ZMAX ? gtab[4 * pg_bin_index(z) + 3] : 2.0 * exp(-z);
+    return p / (p + q);
 }
 
-// Reference form of one attempt (the specification, statement by statement, in `real` arithmetic throughout).
-template <typename real>
-__device__ __forceinline__ bool pg1_attempt_ref(real z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, real& out)
+// Reference form of one attempt: the specification, statement by statement, in fp64 throughout.  The row pass reaches it for the few
+// attempts in 10^5 that fall inside a guard band of the fast forms below and for z >= 8.
+__device__ __forceinline__ bool pg1_attempt_ref(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const double* gtab, double& out)
 {
-    const real t = real(0.64);
-    const real PI = Const<real>::PI;
-    const real K = real(0.125) * PI * PI + real(0.5) * z * z;
-    const real r = pg_tail_weight<real>(z, K);
-    const real u0 = word_to_unif<real>(w0), u1 = word_to_unif<real>(w1), u2 = word_to_unif<real>(w2), V = word_to_unif<real>(w3);
-    real x;
+    const double t = 0.64, PI = 3.14159265358979323846;
+    const double K = 0.125 * PI * PI + 0.5 * z * z;
+    const double u0 = word_to_unif<double>(w0), u1 = word_to_unif<double>(w1), u2 = word_to_unif<double>(w2), V = word_to_unif<double>(w3);
+    const double p = PI / (2.0 * K) * exp(-K * t);
+    double x;
     bool ok = true;
-    if (u0 < r) {
-        x = t - r_div(r_log(u1), K);
-    } else if (z < real(1.5625)) {
-        const real zt = ndtri(u1 * real(0.10564977366685525));       // <= -1/sqrt(t)
-        x = r_rcp(zt * zt);
-        ok = !(u2 > r_exp(real(-0.5) * z * z * x));
+    if (z < PG_ZMAX) {
+        const double* b = gtab + 4 * pg_bin_index(z);
+        const double lam = b[0], c = b[1], M = b[2], q = b[3];
+        if (u0 < p / (p + q)) x = t + (-log(u1)) / K;
+        else {
+            const double Z = 1.25 + c * (-log(u1));
+            x = 1.0 / (Z * Z);
+            ok = !(u2 > exp(-0.5 * (Z - lam) * (Z - lam) - 0.5 * z * z * x - M));
+        }
+    } else if (u0 < p / (p + 2.0 * exp(-z))) {
+        x = t + (-log(u1)) / K;
     } else {
-        const real mu = r_rcp(z), nrm = ndtri(u1);
-        const real ww = mu * nrm * nrm;
-        const real sq = r_sqrt(ww) * r_sqrt(real(4) + ww), den = sq + ww;
-        const real q = den > real(0) ? r_div(real(2) * r_sqrt(ww), den) : real(1);
-        const real x1 = mu * q * q;
-        x = (u2 >= r_div(mu, mu + x1)) ? r_div(mu * mu, x1) : x1;
+        const double mu = 1.0 / z, nrm = ndtri(u1);
+        const double ww = mu * nrm * nrm;
+        const double sq = sqrt(ww) * sqrt(4.0 + ww), den = sq + ww;
+        const double q = den > 0.0 ? 2.0 * sqrt(ww) / den : 1.0;
+        const double x1 = mu * q * q;
+        x = (u2 >= mu / (mu + x1)) ? mu * mu / x1 : x1;
         ok = !(x > t);
     }
-    out = real(0.25) * x;
+    out = 0.25 * x;
     if (!ok) return false;
     // alternating series: accept at odd n if V <= S_n, reject at even n if V > S_n
-    const real e1 = (x > t) ? real(-0.5) * PI * PI * x : real(-2) * r_rcp(x);     // rho_n = (2n+1) exp(n(n+1) e1)
-    real S = real(1) - real(3) * r_exp(real(2) * e1);
+    const double e1 = (x > t) ? -0.5 * PI * PI * x : -2.0 / x;     // rho_n = (2n+1) exp(n(n+1) e1)
+    double S = 1.0 - 3.0 * exp(2.0 * e1);
     if (V <= S) return true;
     for (int n = 2; n <= 200; ++n) {
-        const real rho = real(2 * n + 1) * r_exp(real(n * (n + 1)) * e1);
+        const double rho = (double)(2 * n + 1) * exp((double)(n * (n + 1)) * e1);
         if (n & 1) { S -= rho; if (V <= S) return true; }
         else       { S += rho; if (V > S) return false; }
     }
     return true;
 }
+// ... as a REAL call: inlined into the attempt loop its OCML exponentials and logarithms would set that loop's register pressure.  Behind a
+// call the callee's registers are its own, and the caller saves its live values only on the rare path that calls.
+__device__ __attribute__((noinline)) bool pg1_attempt_ref_call(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const double* gtab, double* out)
+{
+    double o;
+    const bool a = pg1_attempt_ref(z, w0, w1, w2, w3, gtab, o);
+    *out = o;
+    return a;
+}
 
-// fp32 fast path of the same attempt: algebraically identical, arranged as near-straight-line code for a 64-wide wave.
-//   * the mixture test u0 < p/(p+q) is evaluated as u0 (p+q) < p (no reciprocal);
-//   * ONE log serves both the exponential tail (-log u1) and the quantile polynomial (-log 4p(1-p)); 1/K is shared by p and the tail;
-//   * small-z lanes know 1/x = Z^2, so the series exponent needs no reciprocal;
-//   * the rare large-z proposal (z >= 1/t) and the w >= 5 branch of the quantile polynomial sit behind wave-uniform guards.
-__device__ __forceinline__ bool pg1_attempt(float z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, float& out)
+// fp32 fast mode, z < 8: the same attempt as near-straight-line code for a 64-wide wave.  bin = {lam, 1/lam, M, q} of the cell's z-bin.
+//   * the mixture test u0 < p/(p+q) is evaluated as u0 (p+q) < p (no reciprocal); 1/K is shared by p and the tail proposal;
+//   * E = -log u1 serves the tail (X = t + E/K) and the left piece (Z = a + E/lam), whose series exponent -2/X = -2 Z^2 needs no reciprocal;
+//   * the series stops after its first term: rho_2 = 5 e^{6 e1} <= 3.6e-8 for every x an attempt can propose (e^{2 e1} <= 1.93e-3), below
+//     the resolution of fp32 at S_1 ~ 1, so V <= S_1 decides.
+__device__ __forceinline__ bool pg1_attempt(float z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, float4 bin, float& out)
 {
     const float t = 0.64f, PI = 3.14159265358979f;
     const float K = fmaf(0.5f * z, z, 0.125f * PI * PI);
     const float rK = r_rcp(K);
     const float p = (0.5f * PI) * rK * r_exp(-K * t);
-    const bool large = z >= 1.5625f;
-    float q = 0.42259909466742100f;
-    if (__any(large)) q = large ? 2.0f * r_exp(-z) : q;
     const float u0 = word_to_unif<float>(w0), u1 = word_to_unif<float>(w1), u2 = word_to_unif<float>(w2), V = word_to_unif<float>(w3);
-    const bool tail = u0 * (p + q) < p;
-    const float pin = large ? u1 : u1 * 0.10564977366685525f;
-    const float L = -r_log(tail ? u1 : 4.0f * pin * (1.0f - pin));
-    // quantile polynomial (Giles): central branch always, far branch only if some lane needs it
-    float wc = L - 2.5f;
-    float pl = 2.81022636e-08f; pl = fmaf(pl, wc, 3.43273939e-07f); pl = fmaf(pl, wc, -3.5233877e-06f); pl = fmaf(pl, wc, -4.39150654e-06f);
-    pl = fmaf(pl, wc, 0.00021858087f); pl = fmaf(pl, wc, -0.00125372503f); pl = fmaf(pl, wc, -0.00417768164f); pl = fmaf(pl, wc, 0.246640727f);
-    pl = fmaf(pl, wc, 1.50140941f);
-    if (__any(!tail && L >= 5.0f)) {
-        const float wf = r_sqrt(L) - 3.0f;
-        float pf = -0.000200214257f; pf = fmaf(pf, wf, 0.000100950558f); pf = fmaf(pf, wf, 0.00134934322f); pf = fmaf(pf, wf, -0.00367342844f);
-        pf = fmaf(pf, wf, 0.00573950773f); pf = fmaf(pf, wf, -0.0076224613f); pf = fmaf(pf, wf, 0.00943887047f); pf = fmaf(pf, wf, 1.00167406f);
-        pf = fmaf(pf, wf, 2.83297682f);
-        pl = (L >= 5.0f) ? pf : pl;
-    }
-    const float nz = 1.41421356237f * pl * (2.0f * pin - 1.0f);     // Phi^-1(pin)
-    const float nz2 = nz * nz;
-    // small-z left proposal: X = 1/Z^2, kept with probability e^{-z^2 X/2}
-    float x = r_rcp(nz2);
-    bool ok = !(u2 > r_exp(-0.5f * z * z * x));
-    float e1 = -2.0f * nz2;                                          // series exponent -2/x
-    if (__any(large && !tail)) {
-        // IG(1/z, 1) by Michael-Schucany-Haas, rejected beyond t
-        const float mu = r_rcp(z), ww = mu * nz2;
-        const float sq = r_sqrt(ww) * r_sqrt(4.0f + ww), den = sq + ww;
-        const float qq = den > 0.0f ? r_div(2.0f * r_sqrt(ww), den) : 1.0f;
-        const float x1 = mu * qq * qq;
-        const float xl = (u2 >= r_div(mu, mu + x1)) ? r_div(mu * mu, x1) : x1;
-        if (large) { x = xl; ok = !(xl > t); e1 = -2.0f * r_rcp(xl); }
-    }
-    if (tail) { x = fmaf(L, rK, t); ok = true; e1 = -0.5f * PI * PI * x; }
-    out = 0.25f * x;
-    if (!ok) return false;
-    float S = 1.0f - 3.0f * r_exp(2.0f * e1);
-    if (V <= S) return true;
-    for (int n = 2; n <= 200; ++n) {
-        const float rho = (float)(2 * n + 1) * r_exp((float)(n * (n + 1)) * e1);
-        if (n & 1) { S -= rho; if (V <= S) return true; }
-        else       { S += rho; if (V > S) return false; }
-    }
-    return true;
+    const bool tail = u0 * (p + bin.w) < p;
+    const float E = -r_log(u1);
+    const float Z = fmaf(bin.y, E, 1.25f), Z2 = Z * Z;
+    const float xl = r_rcp(Z2), dz = Z - bin.x;
+    const float g = fmaf(-0.5f * dz, dz, fmaf(-0.5f * z * z, xl, -bin.z));       // g(Z) - M <= 0
+    const bool okl = !(u2 > r_exp(g));
+    const float xt = fmaf(E, rK, t);
+    out = 0.25f * (tail ? xt : xl);
+    const float e1 = tail ? -0.5f * PI * PI * xt : -2.0f * Z2;
+    const float S = 1.0f - 3.0f * r_exp(2.0f * e1);
+    return (tail || okl) && V <= S;
 }
 
-// fp64 engine: the same attempt with its accept / reject DECISIONS filtered through fp32.  The four comparisons of an attempt (tail
-// or left piece; left piece kept; second inverse-Gaussian root / truncation at t; first term of the alternating series) are evaluated
-// with the hardware-rate fp32 instructions first.  Each comes with a guard band several times wider than the worst fp32 error of its two
-// sides (derivations in DESIGN.md 4b): outside the band the fp32 outcome IS the fp64 outcome; a lane inside a band (about 4 in 10^5
-// attempts), with z > 10, or with a quantile argument below 2^-22 (where Giles' polynomial is extrapolated) repeats the attempt through
-// pg1_attempt_ref<double>.  Only an ACCEPTED draw is then evaluated in fp64, and only its value (pg1_value_*): one log and one division
-// (tail), one AS 241 rational (left) -- instead of three fp64 exponentials, a log and a quantile per attempt.  Decisions, and therefore
-// which Philox block a cell's draw comes from, are those of the reference form; the value differs from it by rounding only (tests: draw
-// by draw against the oracle, and against pg1_attempt_ref on 2^26 draws).
-//   the series needs no second term: rho_2 = 5 e^{6 e1} <= 3.6e-8 for every x an attempt can propose (e^{2 e1} <= 1.93e-3), less than
-//   the band on V <= S_1, so V > S_1 + band implies V > S_2 (reject) and V <= S_1 - band implies accept.
-// The reference form as a REAL call: the row pass reaches it for about 4 attempts in 10^5, and inlined into the attempt loop its OCML
-// exponentials and logarithms set that loop's register pressure (29 of its 33 VGPR spills).  Behind a call the callee's registers are
-// its own, and the caller saves its live values only on the rare path that calls.
-__device__ __attribute__((noinline)) bool pg1_attempt_ref_call(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double* out)
-{
-    double o;
-    const bool a = pg1_attempt_ref<double>(z, w0, w1, w2, w3, o);
-    *out = o;
-    return a;
-}
-
-enum PgPiece : int { PG_NONE = 0, PG_TAIL = 1, PG_CENTRAL = 2, PG_MID = 3, PG_LARGE = 4 };   // which fp64 evaluation an accepted draw needs
-
-struct PgDecision {
-    bool accept;      // fp32 outcome of the attempt (final unless `unsure`)
-    bool unsure;      // some comparison fell inside its guard band: repeat through pg1_attempt_ref<double>
-    bool second;      // z >= 1/t: the second inverse-Gaussian root was taken
-    int piece;        // PgPiece of the proposal
-    float x;          // fp32 value of the proposal (diagnostic / give-up value)
-};
-
-__device__ __forceinline__ PgDecision pg1_filter(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+// fp64 engine, z < 8: the same attempt with its accept / reject DECISIONS taken in fp32 and its VALUE in fp64.  The three comparisons of an
+// attempt (tail or left piece; left proposal kept; first term of the alternating series) are evaluated with the hardware-rate fp32
+// instructions; each comes with a guard band several times wider than the worst fp32 error of its two sides (derivations in DESIGN.md 4b):
+// outside the band the fp32 outcome IS the fp64 outcome; a lane inside a band (about 1 in 10^4 attempts) or with z >= 8 is flagged `unsure`
+// and the caller repeats the attempt through pg1_attempt_ref.  The value of the proposal -- both pieces: the fp64 logarithm of u1 and one
+// reciprocal -- is evaluated for every lane of the trip (nine lanes in ten accept), so there is nothing to queue or sort.
+//   the series needs no second term: rho_2 <= 3.6e-8 is smaller than the band on V <= S_1, so V > S_1 + band implies V > S_2 (reject) and
+//   V <= S_1 - band implies accept.
+// bin = {lam, 1/lam, M, q} rounded to fp32, cd = 1/lam in fp64 (the value's Z = a + E/lam).  TAB: fm::log through the LDS table.
+template <bool TAB>
+__device__ __forceinline__ bool pg1_attempt_f64(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, float4 bin, double cd,
+                                                [[maybe_unused]] const double2* tab, double& out, bool& unsure)
 {
     const float t = 0.64f, PI = 3.14159265358979f;
     const float zf = (float)z;
     const float K = fmaf(0.5f * zf, zf, 0.125f * PI * PI);
     const float rK = r_rcp(K);
     const float p = (0.5f * PI) * rK * r_exp(-K * t);
-    const bool large = z >= 1.5625;                                  // decided in fp64, like the reference form
-    float q = 0.42259909466742100f;
-    if (__any(large)) q = large ? 2.0f * r_exp(-zf) : q;
     const double u1d = word_to_unif<double>(w1);
     const float u0 = word_to_unif<float>(w0), u1 = (float)u1d, u2 = word_to_unif<float>(w2), V = word_to_unif<float>(w3);   // u1 with RELATIVE accuracy: its log is used
     // (a) tail piece iff u0 (p + q) < p
-    const float da = fmaf(u0, p + q, -p);
+    const float da = fmaf(u0, p + bin.w, -p);
     const bool tail = da < 0.0f;
-    bool unsure = !(fabsf(da) > fmaf(2e-5f, p, 5e-6f * q)) || !(z <= 10.0);
-    const float pin = large ? u1 : u1 * 0.10564977366685525f;
-    const float L = -r_log(tail ? u1 : 4.0f * pin * (1.0f - pin));
-    float wc = L - 2.5f;
-    float pl = 2.81022636e-08f; pl = fmaf(pl, wc, 3.43273939e-07f); pl = fmaf(pl, wc, -3.5233877e-06f); pl = fmaf(pl, wc, -4.39150654e-06f);
-    pl = fmaf(pl, wc, 0.00021858087f); pl = fmaf(pl, wc, -0.00125372503f); pl = fmaf(pl, wc, -0.00417768164f); pl = fmaf(pl, wc, 0.246640727f);
-    pl = fmaf(pl, wc, 1.50140941f);
-    if (__any(!tail && L >= 5.0f)) {
-        const float wf = r_sqrt(L) - 3.0f;
-        float pf = -0.000200214257f; pf = fmaf(pf, wf, 0.000100950558f); pf = fmaf(pf, wf, 0.00134934322f); pf = fmaf(pf, wf, -0.00367342844f);
-        pf = fmaf(pf, wf, 0.00573950773f); pf = fmaf(pf, wf, -0.0076224613f); pf = fmaf(pf, wf, 0.00943887047f); pf = fmaf(pf, wf, 1.00167406f);
-        pf = fmaf(pf, wf, 2.83297682f);
-        pl = (L >= 5.0f) ? pf : pl;
-    }
-    unsure = unsure || (!tail && L > 15.0f);
-    const float nz = 1.41421356237f * pl * (2.0f * pin - 1.0f);
-    const float nz2 = nz * nz;
-    // (b) small-z left piece kept iff u2 <= e^{-z^2 x / 2}
-    float x = r_rcp(nz2);
-    const float thr = r_exp(-0.5f * zf * zf * x);
-    bool ok = !(u2 > thr);
-    unsure = unsure || (!tail && !large && fabsf(u2 - thr) <= 1e-5f);
-    float e1 = -2.0f * nz2;
-    bool second = false;
-    if (__any(large && !tail)) {
-        // (c) IG(1/z, 1): second root iff u2 >= mu / (mu + x1); kept iff x <= t
-        const float mu = r_rcp(zf), ww = mu * nz2;
-        const float sq = r_sqrt(ww) * r_sqrt(4.0f + ww), den = sq + ww;
-        const float qq = den > 0.0f ? r_div(2.0f * r_sqrt(ww), den) : 1.0f;
-        const float x1 = mu * qq * qq;
-        const float thr2 = r_div(mu, mu + x1);
-        const bool sec = u2 >= thr2;
-        const float xl = sec ? r_div(mu * mu, x1) : x1;
-        if (large) {
-            x = xl; ok = !(xl > t); e1 = -2.0f * r_rcp(xl); second = sec;
-            unsure = unsure || (!tail && (fabsf(u2 - thr2) <= 1e-5f || fabsf(xl - t) <= 2e-5f || !(den > 0.0f)));
-        }
-    }
-    if (tail) { x = fmaf(L, rK, t); ok = true; e1 = -0.5f * PI * PI * x; }
-    // (d) V <= S_1 = 1 - 3 e^{2 e1}
+    bool uns = !(fabsf(da) > fmaf(2e-5f, p, 5e-6f * bin.w)) || !(z < PG_ZMAX);
+    // (b) left proposal kept iff u2 <= e^{g(Z) - M}
+    const float E = -r_log(u1);
+    const float Z = fmaf(bin.y, E, 1.25f), Z2 = Z * Z;
+    const float xl = r_rcp(Z2), dz = Z - bin.x;
+    const float thr = r_exp(fmaf(-0.5f * dz, dz, fmaf(-0.5f * zf * zf, xl, -bin.z)));
+    uns = uns || (!tail && fabsf(u2 - thr) <= 3e-5f);
+    const bool ok = tail || !(u2 > thr);
+    // (c) V <= S_1 = 1 - 3 e^{2 e1}
+    const float xt = fmaf(E, rK, t);
+    const float e1 = tail ? -0.5f * PI * PI * xt : -2.0f * Z2;
     const float S = 1.0f - 3.0f * r_exp(2.0f * e1);
-    PgDecision d;
-    d.accept = ok && V <= S;
-    d.unsure = unsure || (ok && fabsf(V - S) <= 1e-6f);
-    d.second = second;
-    d.x = x;
-    // the quantile range of the left piece, from the fp64 argument exactly as AS 241 splits it
-    const double pa = large ? u1d : u1d * 0.10564977366685525;
-    d.piece = tail ? PG_TAIL : (large ? PG_LARGE : (fabs(pa - 0.5) <= 0.425 ? PG_CENTRAL : PG_MID));
-    return d;
+    unsure = uns || (ok && fabsf(V - S) <= 1e-6f);
+    // the value: tail X = t + E/K, left X = 1/Z^2 with Z = a + E/lam -- E/den or 1/den from ONE reciprocal
+    const double PId = 3.14159265358979323846;
+    double Ed;
+    if constexpr (TAB) Ed = -fm::log(u1d, tab); else Ed = -fm::log(u1d);
+    const double Zd = fma(cd, Ed, 1.25);
+    const double den = tail ? fma(0.5 * z, z, 0.125 * PId * PId) : Zd * Zd;
+    const double r = fm::rcp(den);
+    const double qd = Ed * r;
+    out = 0.25 * (tail ? 0.64 + fma(fma(-den, qd, Ed), r, qd) : r);
+    return ok && V <= S;
 }
 
-// ---- fp64 value of an accepted proposal, one function per piece (each returns X; omega = X / 4)
-__device__ __forceinline__ double pg1_value_tail(double z, uint32_t w1)          // X = t - log(u1) / K
+// one whole attempt in the calling lane's own control flow (debug sampler); gtab: the [PG_NBIN][4] table in global memory
+__device__ __forceinline__ bool pg1_attempt(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const double* gtab, double& out)
 {
-    const double PId = 3.14159265358979323846;
-    return 0.64 - fm::div(fm::log(word_to_unif<double>(w1)), fma(0.5 * z, z, 0.125 * PId * PId));
-}
-__device__ __forceinline__ double pg1_value_tail(double z, uint32_t w1, const double2* tab)      // the same with the LDS log table
-{
-    const double PId = 3.14159265358979323846;
-    return 0.64 - fm::div(fm::log(word_to_unif<double>(w1), tab), fma(0.5 * z, z, 0.125 * PId * PId));
-}
-__device__ __forceinline__ double pg1_value_central(uint32_t w1)                 // X = 1 / Z^2, Z = Phi^-1(pa) = qc n / d
-{
-    const double qc = word_to_unif<double>(w1) * 0.10564977366685525 - 0.5;
-    double n, d;
-    as241::central(fma(-qc, qc, 0.180625), n, d);
-    const double ratio = fm::div(d, qc * n);
-    return ratio * ratio;
-}
-__device__ __forceinline__ double pg1_value_mid(uint32_t w1, const double2* tab = nullptr)       // X = 1 / Z^2, |Z| = n / d
-{
-    const double pa = word_to_unif<double>(w1) * 0.10564977366685525;
-    const double r = fm::sqrt(-(tab ? fm::log(pa, tab) : fm::log(pa)));
-    double n, d;
-    as241::mid(r, n, d);
-    if (__any(r > 5.0)) as241::far_fix(r, n, d);            // quantile arguments below e^-25: a real call
-    const double ratio = fm::div(d, n);
-    return ratio * ratio;
-}
-// z >= 1/t: IG(mu = 1/z, 1) from Z = Phi^-1(u1) (Michael-Schucany-Haas): with w = mu Z^2, x1 = 4 mu / (sqrt(4 + w) + sqrt(w))^2, the
-// second root is mu^2 / x1 (the same roots as the reference form's 2 sqrt(w) / (sqrt(w) sqrt(4 + w) + w), divided through by sqrt(w))
-__device__ __attribute__((noinline)) double pg1_value_large(double z, uint32_t w1, bool second)      // a real call: z >= 1/t left pieces are rare
-{
-    const double Z = ndtri(word_to_unif<double>(w1));
-    const double mu = fm::rcp(z), w = mu * Z * Z;
-    const double sm = fm::sqrt(4.0 + w) + sqrt(w);
-    return second ? 0.25 * mu * sm * sm : fm::div(4.0 * mu, sm * sm);
-}
-
-// one whole attempt in the calling lane's own control flow (debug sampler, item-free callers); the row pass batches the value
-// evaluations by piece instead (erm_kernels.hpp, PG phase)
-__device__ __forceinline__ bool pg1_attempt(double z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double& out)
-{
-    const PgDecision d = pg1_filter(z, w0, w1, w2, w3);
-    bool accept = d.accept;
-    out = 0.25 * (double)d.x;
-    const bool go = accept && !d.unsure;
-    if (__any(go && d.piece == PG_TAIL)) { const double x = pg1_value_tail(z, w1); if (go && d.piece == PG_TAIL) out = 0.25 * x; }
-    if (__any(go && d.piece == PG_CENTRAL)) { const double x = pg1_value_central(w1); if (go && d.piece == PG_CENTRAL) out = 0.25 * x; }
-    if (__any(go && d.piece == PG_MID)) { const double x = pg1_value_mid(w1); if (go && d.piece == PG_MID) out = 0.25 * x; }
-    if (__any(go && d.piece == PG_LARGE)) { const double x = pg1_value_large(d.piece == PG_LARGE ? z : 2.0, w1, d.second); if (go && d.piece == PG_LARGE) out = 0.25 * x; }
-    if (__any(d.unsure)) {
-        double o2;
-        const bool a2 = pg1_attempt_ref<double>(z, w0, w1, w2, w3, o2);
-        if (d.unsure) { accept = a2; out = o2; }
-    }
+    const double* b = gtab + 4 * pg_bin_index(z);
+    bool unsure;
+    bool accept = pg1_attempt_f64<false>(z, w0, w1, w2, w3, make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]), b[1], nullptr, out, unsure);
+    if (unsure) accept = pg1_attempt_ref(z, w0, w1, w2, w3, gtab, out);
     return accept;
+}
+__device__ __forceinline__ bool pg1_attempt(float z, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const double* gtab, float& out)
+{
+    if (!(z < (float)PG_ZMAX)) { double o; const bool a = pg1_attempt_ref((double)z, w0, w1, w2, w3, gtab, o); out = (float)o; return a; }
+    const double* b = gtab + 4 * pg_bin_index(z);
+    return pg1_attempt(z, w0, w1, w2, w3, make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]), out);
 }
 
 // draw addressed by a stream: attempt k consumes block k
-template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c)
+template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c, const double* gtab)
 {
     const real z = real(0.5) * r_abs(c);
     real out = real(0);
     for (int tries = 0; tries < MAX_TRIES; ++tries) {
         const uint32_t w0 = s.next(), w1 = s.next(), w2 = s.next(), w3 = s.next();
-        if (pg1_attempt(z, w0, w1, w2, w3, out)) break;
+        if (pg1_attempt(z, w0, w1, w2, w3, gtab, out)) break;
     }
     return out;
 }

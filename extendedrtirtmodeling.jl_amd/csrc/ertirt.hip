@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types only: the library is bound at run time (dlopen) and only by subject-sharded chains
 #include <dlfcn.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -15,6 +16,7 @@
 #include <vector>
 #include "ertirt.h"
 #include "erm_kernels.hpp"
+#include "erm_geometry.hpp"
 
 using namespace erm;
 
@@ -43,6 +45,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::mutex mu;
     int load() {
@@ -60,8 +63,9 @@ struct Rccl {
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString || !AllReduce || !CommInitAll || !GroupStart || !GroupEnd) { lib = nullptr; return fail(ERM_ERR_STATE, "RCCL library lacks an expected symbol"); }
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !CommCount || !GetErrorString || !AllReduce || !CommInitAll || !GroupStart || !GroupEnd) { lib = nullptr; return fail(ERM_ERR_STATE, "RCCL library lacks an expected symbol"); }
         return 0;
     }
 };
@@ -209,35 +213,14 @@ template <typename real> struct Engine : EngineBase {
         }
         return fail(ERM_ERR_ARG, "unknown model");
     }
-    int nstat(int phase) const {
-        if (cfg.model == ERM_MODEL_MLIRT) return 4;
-        return m_cq() ? (phase == 0 ? 8 : 2) : 5;
-    }
-    int stat_sizes(int phase) const {
-        const int pp = p();
-        int ng = pp + 1;
-        if (fam_rt(cfg.model)) ng = 2 * pp + 4; else if (fam_lq(cfg.model)) ng = 2 * pp + 8; else if (m_cq()) ng = phase == 0 ? 1 : 2;
-        return nstat(phase) * J + ng + ngx();
-    }
     // LatentQr with sigp_mode 1 also accumulates the 1/nu-weighted Gram entries of [1 X theta | u]
     int ngx() const {
         if (cfg.model != ERM_MODEL_LATENTQR || cfg.sigp_mode != 1) return 0;
         const int q = p() + 1;
         return q * (q + 1) / 2 + q + 1;
     }
-    // dynamic LDS of a row pass = fixed part | (fused: tiny-step scratch) | tail, where the tail holds the per-wave item accumulators
-    // [nWaves][NSTAT][J] and -- overlaid on them, the two are never live together -- the fp64 engine's PG-phase value queues
-    // (4 pieces x 128 entries x 8 bytes per wave)
-    size_t tail_lds(int phase, int nWaves) const {
-        const size_t acc = (size_t)nWaves * nstat(phase) * J * sizeof(double);
-        const size_t q = (sizeof(real) == 8 && phase == 0) ? (size_t)nWaves * 4 * 128 * 8 : 0;
-        return std::max(acc, q);
-    }
-    size_t pass_lds(int phase, int nWaves) const {
-        const int ng = stat_sizes(phase) - nstat(phase) * J;
-        size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * (size_t)ng;
-        return d * sizeof(double) + ((size_t)NITEMARR * J + (size_t)nWaves * 4 * rows_per_wave + (size_t)rows_per_block * (Fk + 4)) * sizeof(real) + 8 + tail_lds(phase, nWaves);
-    }
+    Geom G;                                          // launch geometry and LDS layout: decided by plan_geometry (erm_geometry.hpp) and nowhere else
+    DevBuf dPgTab;                                   // the Polya-Gamma proposal table [PG_NBIN][4] (erm_rng.hpp, pg_bin)
 
     int init() override {
         N = cfg.n_subj; J = cfg.n_item; F = cfg.n_feat;
@@ -260,78 +243,18 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipEventCreate(&ev1));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 3 * sizeof(Ctl), hipHostMallocDefault));
 
-        // ---- geometry: W lanes per subject
-        if (cfg.lanes_per_row > 0) {
-            W = cfg.lanes_per_row;
-            if (W > 64 || (W & (W - 1))) return fail(ERM_ERR_ARG, "lanes_per_row must be a power of two <= 64");
-        } else {
-            // W only shapes the row-sum phase (the PG phase walks flattened cells): few items per lane keeps the dependent
-            // load batches short, many subjects per wave-iteration keeps the number of iterations low; W = 8 balances both
-            // for nItem around 50 (measured); never more lanes than items (rounded up to a power of two).
-            W = 8;
-            while (W > 1 && W / 2 >= J) W /= 2;
+        // ---- geometry (pure host function, CPU-tested: erm_geometry.hpp)
+        {
+            GeomIn gi;
+            gi.model = cfg.model; gi.f64 = sizeof(real) == 8; gi.N = N; gi.J = J; gi.Fk = Fk; gi.ngx = ngx();
+            gi.lanes_per_row = cfg.lanes_per_row; gi.block_threads = cfg.block_threads; gi.grid_blocks = cfg.grid_blocks;
+            gi.cu_count = cu_count; gi.no_fuse = (cfg.flags & ERM_FLAG_NO_FUSE) != 0;
+            std::string msg;
+            if (plan_geometry(gi, G, msg) != 0) return fail(ERM_ERR_ARG, msg);
+            W = G.W; logW = G.logW; IPL = G.IPL; block_threads = G.block_threads; grid_blocks = G.grid_blocks; n_groups = G.n_groups;
+            rows_per_block = G.rows_per_block; rows_per_wave = G.rows_per_wave; fuse_ok = G.fused;
+            for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = G.lds_pass[ph]; ns[ph] = G.ns[ph]; }
         }
-        logW = 0; while ((1 << logW) < W) ++logW;
-        IPL = (J + W - 1) / W;
-        const int max_threads = sizeof(real) == 8 ? (cfg.model == ERM_MODEL_LATENTQR ? ERM_F64_THREADS_LATENTQR : ERM_F64_THREADS) : ERM_F32_THREADS;      // = the kernels' launch bounds
-        block_threads = cfg.block_threads > 0 ? cfg.block_threads : max_threads;
-        if (block_threads % 64 || block_threads > max_threads) return fail(ERM_ERR_ARG, "block_threads must be a multiple of 64, <= " + std::to_string(max_threads) + " for this model and precision");
-        // the per-wave item accumulators (nWaves x NSTAT x nItem doubles) dominate LDS for long tests: fewer waves per workgroup then
-        if (cfg.block_threads == 0) {
-            while (block_threads > 64) {
-                const size_t acc = (size_t)(block_threads / 64) * nstat(0) * J * sizeof(double);
-                const size_t fixed = (size_t)NITEMARR * J * sizeof(real) + (size_t)(stat_sizes(0) + 5 * J + 2 * J + TINY_WORK + 2 * PMAX * PMAX + 64) * sizeof(double);
-                if (acc + fixed <= 120 * 1024) break;
-                block_threads = std::max(64, block_threads / 2 / 64 * 64);
-            }
-        }
-        // small data sets: a workgroup whose threads would get fewer than two cells each in the PG phase is halved (down to 256 threads) -- its head, its
-        // barriers and its reductions are paid per wave (fp64, 50 items: 1 000 subjects 37.2 -> 32.0 us per sweep, 10 000 subjects 42.8 -> 40.4)
-        if (cfg.block_threads == 0 && cfg.grid_blocks == 0) {
-            while (block_threads > 256) {
-                const int nw = block_threads / 64;
-                const int pc = sizeof(real) == 8 ? 1 : std::max(1, 16 / nw);
-                const int64_t g = std::max<int64_t>(1, std::min<int64_t>((N + nw - 1) / nw, (int64_t)cu_count * pc));
-                const int64_t rows = (N + g - 1) / g;
-                if (rows * J >= 2 * (int64_t)block_threads) break;
-                block_threads = std::max(256, block_threads / 2 / 64 * 64);
-            }
-        }
-        const int nWaves = block_threads / 64;
-        const int64_t need = (N + nWaves - 1) / nWaves;         // at least one subject per wave
-        const int per_cu = sizeof(real) == 8 ? 1 : std::max(1, 16 / nWaves);       // resident workgroups per CU (the fp64 kernel's registers admit one)
-        grid_blocks = cfg.grid_blocks > 0 ? cfg.grid_blocks : (int)std::min<int64_t>(need, (int64_t)cu_count * per_cu);
-        if (grid_blocks < 1) grid_blocks = 1;
-        // each workgroup owns a contiguous range of subjects, split evenly over its waves
-        // (the per-subject LDS caches grow with the rows a workgroup owns: very long data sets get more workgroups than CUs)
-        // (more workgroups than the chip holds at once run in rounds, and a partial round costs as much as a full one: past one round the count
-        // grows by whole rounds -- the smallest number of rounds whose workgroups fit their subjects into LDS)
-        const int slots = cu_count * per_cu;
-        for (;;) {
-            rows_per_block = (N + grid_blocks - 1) / grid_blocks;
-            grid_blocks = (int)((N + rows_per_block - 1) / rows_per_block);
-            rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
-            // fused sweeps take subjects off wave 0 (it runs the tiny step's structural chain first): the other waves' slices grow
-            if (fused() && nWaves > 1) rows_per_wave = (int)((rows_per_block + nWaves - 2) / (nWaves - 1)) + 1;
-            for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = pass_lds(ph, nWaves); ns[ph] = stat_sizes(ph); }
-            // only the row pass has to fit: the fewest rounds win (fp64, 200 000 x 50: one round 195 us, two 212; 500 000 x 100: 2 rounds 857 us, 4 rounds
-            // 884; 2 000 000 x 50: 8 rounds 1 829 us, 12 rounds 1 999).  When the tiny step's scratch no longer fits beside the larger slices the sweep
-            // falls back to the two-kernel schedule below (tiny step in a kernel of its own instead of every workgroup's head)
-            const size_t need_lds = std::max(lds_pass[0], lds_pass[1]);
-            const bool cells_ok = rows_per_block * J < ((int64_t)1 << 22);      // the PG phase's cell indices (erm_kernels.hpp, `locate`: exact below 2^22)
-            if ((need_lds <= 158 * 1024 && cells_ok) || cfg.grid_blocks > 0 || rows_per_block <= nWaves) break;
-            // (the count above is the smallest with that many subjects per workgroup -- 767, not 768: whole rounds are counted rounding up)
-            if (grid_blocks >= slots) grid_blocks = ((grid_blocks + slots - 1) / slots + 1) * slots;
-            else grid_blocks = std::min(slots, grid_blocks + std::max(1, grid_blocks / 4));
-        }
-        if (getenv("ERM_NO_FUSE")) fuse_ok = false;                       // diagnostics: the two-kernel schedule (stand-alone tiny kernel)
-        if (!fuse_ok || (fused() && fused_lds() > 160 * 1024)) {       // the tiny step's scratch does not fit next to the pass layout (or ERM_NO_FUSE): keep the two-kernel schedule
-            fuse_ok = false;
-            rows_per_wave = (int)((rows_per_block + nWaves - 1) / nWaves);
-            for (int ph = 0; ph < 2; ++ph) lds_pass[ph] = pass_lds(ph, nWaves);
-        }
-        if (lds_pass[0] > 160 * 1024 || lds_pass[1] > 160 * 1024) return fail(ERM_ERR_ARG, "LDS footprint too large; lower block_threads or raise grid_blocks");
-        if (rows_per_block * J >= ((int64_t)1 << 22)) return fail(ERM_ERR_ARG, "a workgroup would own 2^22 cells or more; raise grid_blocks");
 
         // ---- device memory
         rows_cap = (int64_t)cfg.n_iter * cfg.n_chain;
@@ -347,8 +270,6 @@ template <typename real> struct Engine : EngineBase {
         rc |= dZeta.alloc((size_t)N * sizeof(real));
         for (int k = 0; k < 2; ++k) rc |= dParB[k].alloc((size_t)par_size(J) * sizeof(double));
         rc |= dCst.alloc((size_t)cst_size(J) * sizeof(double));
-        n_groups = (grid_blocks + GROUP - 1) / GROUP;
-        if (n_groups > TINY_THREADS) return fail(ERM_ERR_ARG, "grid too large");
         rc |= dSlab0.alloc((size_t)grid_blocks * ns[0] * sizeof(double));
         for (int k = 0; k < 2; ++k) rc |= dGslab0B[k].alloc((size_t)n_groups * ns[0] * sizeof(double));
         rc |= dGcnt.alloc((size_t)2 * n_groups * sizeof(unsigned int));
@@ -367,13 +288,14 @@ template <typename real> struct Engine : EngineBase {
             if (cfg.model == ERM_MODEL_CROSSQR) {
                 // Post.qr of GibbsRtIrtCrossQr carries vec(nu) (N*J values) per sweep (src/GibbsRtIrtCross.pl.jl:65,296): kept on the device
                 // when it fits the budget (ERM_NU_TRACE_MAX_GB, default 16), otherwise only nu's running mean is available
-                const char* e = getenv("ERM_NU_TRACE_MAX_GB");
-                const double cap_gb = e ? atof(e) : 16.0;
+                const double cap_gb = cfg.nu_trace_max_gb > 0.0 ? cfg.nu_trace_max_gb : 16.0;
                 const double need_gb = (double)rows_cap * (double)NJ * sizeof(real) / 1073741824.0;
                 if (need_gb <= cap_gb) rc |= dTrNu.alloc((size_t)rows_cap * NJ * sizeof(real));
             }
         }
+#ifdef ERM_TIMELINE_BUILD
         if (getenv("ERM_TIMELINE")) rc |= dDbgTs.alloc(2 * 16 * 16 * sizeof(unsigned long long));
+#endif
         if (rc) return rc;
         if (cfg.profile) {
             pass_ev.resize(2 * 4096);
@@ -390,6 +312,12 @@ template <typename real> struct Engine : EngineBase {
             std::vector<real> ones(dNu.bytes / sizeof(real), real(1));
             H2D(dNu.p, ones.data(), dNu.bytes);
         }
+        {   // the Polya-Gamma proposal table, computed here in fp64 (the oracle restates the same closed form)
+            std::vector<double> tab((size_t)PG_NBIN * 4);
+            for (int k = 0; k < PG_NBIN; ++k) pg_bin(k, &tab[(size_t)4 * k]);
+            if (int rc2 = dPgTab.alloc(tab.size() * sizeof(double))) return rc2;
+            H2D(dPgTab.p, tab.data(), tab.size() * sizeof(double));
+        }
         timing.lanes_per_row = W; timing.block_threads = block_threads; timing.grid_blocks = grid_blocks;
         timing.lds_bytes = (int32_t)std::max(lds_pass[0], lds_pass[1]); timing.cu_count = cu_count;
         return configure_kernels();
@@ -400,20 +328,28 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<MODEL, real, PHASE, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         return 0;
     }
-    // the fused kernel appends the tiny step's scratch (statistics, partials, structural scratch, x'x, parameter block) to the pass layout
-    size_t fused_lds() const { return lds_pass[0] + 8 + (size_t)(2 * ns[0] + TINY_WORK + 2 * PMAX * PMAX + par_size(J) + 3 * J + 2) * sizeof(double); }
-    size_t tiny_lds() const { return (size_t)tiny_lds_doubles(ns[0], m_cq() ? ns[1] : 0, J) * sizeof(double); }
+    // dynamic LDS limits of every kernel this engine launches; the planner's figure for the kernels' STATIC LDS is checked against the compiler's
+    size_t fused_lds() const { return G.lds_fused; }
+    size_t tiny_lds() const { return G.lds_tiny; }
+    template <int MODEL, int PHASE, bool FUSED> int check_static_lds() {
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&pass_kernel<MODEL, real, PHASE, FUSED>)));
+        if (fa.sharedSizeBytes > G.lds_static[PHASE])
+            return fail(ERM_ERR_STATE, "internal: pass_kernel declares " + std::to_string(fa.sharedSizeBytes) + " B of static LDS, the planner assumes " + std::to_string(G.lds_static[PHASE]));
+        return 0;
+    }
     int configure_kernels() {
         const int tl = (int)tiny_lds();
-        if (tl > 160 * 1024) return fail(ERM_ERR_ARG, "tiny-step LDS footprint too large");
         return dispatch([&](auto m) -> int {
             constexpr int M = decltype(m)::value;
+            if (int rc = check_static_lds<M, 0, false>()) return rc;
             if (int rc = set_lds_attr<M, 0, false>(lds_pass[0])) return rc;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<M, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
             if constexpr (!fam_cq(M)) {
-                if (fused()) { if (int rc = set_lds_attr<M, 0, true>(fused_lds())) return rc; }
+                if (fused()) { if (int rc = check_static_lds<M, 0, true>()) return rc; if (int rc = set_lds_attr<M, 0, true>(fused_lds())) return rc; }
             }
             if constexpr (fam_cq(M)) {
+                if (int rc = check_static_lds<M, 1, false>()) return rc;
                 if (int rc = set_lds_attr<M, 1, false>(lds_pass[1])) return rc;
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<M, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
             }
@@ -447,7 +383,7 @@ template <typename real> struct Engine : EngineBase {
         PassArgs<real> a{};
         a.Y = dY.as<uint8_t>(); a.C = dC.as<real>(); a.omega = dOmega.as<real>(); a.nu = dNu.as<real>(); a.X = dX.as<real>();
         a.theta = dTheta.as<real>(); a.zeta = dZeta.as<real>();
-        a.par = dParB[cur].template as<double>(); a.cst = dCst.as<double>();
+        a.par = dParB[cur].template as<double>(); a.cst = dCst.as<double>(); a.pgtab = dPgTab.as<double>();
         a.slab = phase == 0 ? dSlab0.as<double>() : dSlab1.as<double>();
         a.gslab = phase == 0 ? dGslab0B[fz ? 1 - cur : cur].template as<double>() : dGslab1.as<double>();
         a.gcnt = dGcnt.as<unsigned int>() + (phase == 0 ? 0 : n_groups);
@@ -463,10 +399,7 @@ template <typename real> struct Engine : EngineBase {
         a.dbg_stop = diag_stop("ERM_PASS_STOP");
         a.dbg_ts = dDbgTs.as<unsigned long long>();
         a.row_base = (uint32_t)row_base;
-        {   // the accumulator / queue tail closes the launch's dynamic LDS (every part before it is a multiple of 8 bytes)
-            const size_t total = fz ? fused_lds() : lds_pass[phase];
-            a.acc_off = (int)((total - tail_lds(phase, block_threads / 64)) & ~(size_t)7);
-        }
+        a.acc_off = fz ? G.acc_off_fused : G.acc_off[phase];     // the accumulators close the launch's dynamic LDS
         return a;
     }
     TinyArgs tiny_args(int mode, int first, bool fz = false) const {
@@ -611,7 +544,7 @@ template <typename real> struct Engine : EngineBase {
         int64_t k = 0;
         if (nsweeps > 0) { if (int rc = enqueue_sweep<MODEL>(true, false)) return rc; k = 1; }
         // (a callback exchange synchronises with the host once per pass and cannot be captured; RCCL's all-gather is a stream operation)
-        const bool use_graph = exch == nullptr && getenv("ERM_NO_GRAPH") == nullptr;
+        const bool use_graph = exch == nullptr && (cfg.flags & ERM_FLAG_NO_GRAPH) == 0;
         // profile mode brackets ONE sweep's row pass with events before every replayed block of GRAPH_SWEEPS sweeps (and every
         // PROFILE_STRIDE-th sweep of the remainder): a live sample of the timed region whose bracketing overhead (~4.6 us per pair)
         // stays negligible for the whole-job timing, while the bulk of the sweeps still runs from the graph
@@ -783,6 +716,9 @@ template <typename real> struct Engine : EngineBase {
         if (Fk > 0 && !X) return fail(ERM_ERR_ARG, "X is required when n_feat > 0");
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamSynchronize(stream));
+        // the resident buffers are overwritten from here on: until this call succeeds the engine holds NO data set (a rejected Y / logT must
+        // not leave the previous set's flags -- and its statistics -- standing over the new bytes)
+        has_data = false; stats_valid = false;
         const size_t NJ = (size_t)N * J;
         const double Ntot = sharded() ? (double)n_total : (double)N;      // a shard's column sums are completed over the devices
         const int pp = p();
@@ -899,6 +835,7 @@ template <typename real> struct Engine : EngineBase {
         if (gen == 3 && !tr->rho) return fail(ERM_ERR_ARG, "truth needs rho");
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamSynchronize(stream));
+        has_data = false; stats_valid = false;
         // truth vector: a b lambda sig2t rho | chol(Sigp) | beta
         std::vector<double> tv((size_t)5 * J + 3 + 2 * PMAX + 2, 0.0);
         for (int j = 0; j < J; ++j) {
@@ -1339,8 +1276,13 @@ struct erm_farm {
     std::vector<int> dev;                                // dev[l]: its device
     std::vector<int> udev;                               // distinct devices, in order of first use
     std::vector<ncclComm_t> comms;                       // one communicator rank per distinct device (empty until the first reduction over > 1 device)
+    std::vector<hipStream_t> rstream;                    // one stream per distinct device for the reduction (never the NULL stream: the engines' streams are non-blocking)
     bool used_rccl = false;
-    ~erm_farm() { for (auto c : comms) if (c) (void)g_rccl.CommDestroy(c); }
+    erm_farm_timing tm{};
+    ~erm_farm() {
+        for (auto c : comms) if (c) (void)g_rccl.CommDestroy(c);
+        for (size_t d = 0; d < rstream.size(); ++d) if (rstream[d]) { (void)hipSetDevice(udev[d]); (void)hipStreamDestroy(rstream[d]); }
+    }
     // runs f(l) for every chain on its own host thread; returns the first non-zero code (its message becomes this thread's last error)
     template <typename Fn> int parallel(Fn&& f) {
         const int n = (int)eng.size();
@@ -1467,7 +1409,21 @@ int erm_farm_get_state(erm_farm_handle f, int32_t chain, erm_state* st)
 int erm_farm_run(erm_farm_handle f, int64_t nsweeps)
 {
     CHK_F;
-    return f->parallel([&](int l) { return f->eng[l]->e->run(nsweeps); });
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = f->parallel([&](int l) { return f->eng[l]->e->run(nsweeps); });
+    f->tm.run_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+int erm_farm_get_timing(erm_farm_handle f, erm_farm_timing* out, double* run_ms)
+{
+    CHK_F;
+    if (!out) return fail(ERM_ERR_ARG, "out is NULL");
+    *out = f->tm;
+    out->n_devices = (int32_t)f->udev.size();
+    out->rccl_ranks = 0;
+    if (!f->comms.empty() && f->comms[0]) { int n = 0; RCCLCHK(g_rccl.CommCount(f->comms[0], &n)); out->rccl_ranks = n; }
+    if (run_ms) for (size_t l = 0; l < f->eng.size(); ++l) run_ms[l] = f->eng[l]->e->timing.run_ms;
+    return 0;
 }
 int erm_farm_reset_trace(erm_farm_handle f)
 {
@@ -1497,6 +1453,7 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
 {
     CHK_F;
     if (!out) return fail(ERM_ERR_ARG, "state is NULL");
+    const auto t0 = std::chrono::steady_clock::now();
     const int64_t total = erm_farm_post_count(f);
     if (total <= 0) return fail(ERM_ERR_STATE, "no post-burn-in sweeps recorded");
     const int64_t len = f->eng[0]->e->summary_len();
@@ -1505,28 +1462,44 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
     std::vector<DevBuf> acc(nd);
     for (int d = 0; d < nd; ++d) {
         HIPCHK(hipSetDevice(f->udev[d]));
-        if (int rc = acc[d].alloc((size_t)len * sizeof(double))) return rc;      // zeroed
+        if (int rc = acc[d].alloc((size_t)len * sizeof(double))) return rc;      // zeroed, complete on return
     }
     for (size_t l = 0; l < f->eng.size(); ++l) {
         int d = 0;
         while (f->udev[d] != f->dev[l]) ++d;
-        if (int rc = f->eng[l]->e->summary_add(acc[d].as<double>())) return fail(rc, "chain " + std::to_string(l) + ": " + g_err);
+        if (int rc = f->eng[l]->e->summary_add(acc[d].as<double>())) return fail(rc, "chain " + std::to_string(l) + ": " + g_err);      // synchronises its stream
     }
-    // one all-reduce over the devices (RCCL over xGMI).  ERM_FARM_FORCE_RCCL=1 takes this path with a one-device communicator too (tests)
-    const bool force = getenv("ERM_FARM_FORCE_RCCL") != nullptr;
+    // one all-reduce over the devices (RCCL over xGMI), each rank on a stream of its own.  ERM_FLAG_FARM_FORCE_RCCL takes this path with a
+    // one-device communicator too (tests)
+    const bool force = (f->cfg.flags & ERM_FLAG_FARM_FORCE_RCCL) != 0;
+    f->used_rccl = false;
+    f->tm.allreduce_ms = 0.0;
     if (nd > 1 || force) {
         if (int rc = g_rccl.load()) return rc;
+        if (f->rstream.empty()) {
+            f->rstream.assign(nd, nullptr);
+            for (int d = 0; d < nd; ++d) { HIPCHK(hipSetDevice(f->udev[d])); HIPCHK(hipStreamCreateWithFlags(&f->rstream[d], hipStreamNonBlocking)); }
+        }
         if (f->comms.empty()) {
             f->comms.assign(nd, nullptr);
-            RCCLCHK(g_rccl.CommInitAll(f->comms.data(), nd, f->udev.data()));
+            const ncclResult_t r = g_rccl.CommInitAll(f->comms.data(), nd, f->udev.data());
+            if (r != ncclSuccess) { f->comms.clear(); return fail(ERM_ERR_STATE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
         }
-        RCCLCHK(g_rccl.GroupStart());
-        for (int d = 0; d < nd; ++d) {
-            HIPCHK(hipSetDevice(f->udev[d]));
-            RCCLCHK(g_rccl.AllReduce(acc[d].p, acc[d].p, (size_t)len, ncclDouble, ncclSum, f->comms[d], nullptr));
+        const auto a0 = std::chrono::steady_clock::now();
+        // a group that has been started is always ended, whatever happens inside it
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) return fail(ERM_ERR_STATE, std::string("ncclGroupStart: ") + g_rccl.GetErrorString(r));
+        std::string what;
+        for (int d = 0; d < nd && r == ncclSuccess; ++d) {
+            if (hipSetDevice(f->udev[d]) != hipSuccess) { what = "hipSetDevice"; r = ncclUnhandledCudaError; break; }
+            r = g_rccl.AllReduce(acc[d].p, acc[d].p, (size_t)len, ncclDouble, ncclSum, f->comms[d], f->rstream[d]);
+            if (r != ncclSuccess) what = "ncclAllReduce";
         }
-        RCCLCHK(g_rccl.GroupEnd());
-        for (int d = 0; d < nd; ++d) { HIPCHK(hipSetDevice(f->udev[d])); HIPCHK(hipStreamSynchronize(nullptr)); }
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (r != ncclSuccess) return fail(ERM_ERR_STATE, what + ": " + g_rccl.GetErrorString(r));
+        if (re != ncclSuccess) return fail(ERM_ERR_STATE, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(re));
+        for (int d = 0; d < nd; ++d) { HIPCHK(hipSetDevice(f->udev[d])); HIPCHK(hipStreamSynchronize(f->rstream[d])); }
+        f->tm.allreduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count();
         f->used_rccl = true;
     }
     std::vector<double> m((size_t)len);
@@ -1534,7 +1507,9 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
     HIPCHK(hipMemcpy(m.data(), acc[0].p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost));
     const double inv = 1.0 / (double)total;
     for (auto& v : m) v *= inv;
-    return f->eng[0]->e->summary_unpack(m.data(), out);
+    const int rc = f->eng[0]->e->summary_unpack(m.data(), out);
+    f->tm.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 const char* erm_last_error(void) { return g_err.c_str(); }
@@ -1549,11 +1524,18 @@ int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32
     if (int rc = dout.alloc(n * sizeof(double))) return rc;
     if (par0) { if (int rc = d0.alloc(n * sizeof(double))) return rc; H2D(d0.p, par0, n * sizeof(double)); }
     if (par1) { if (int rc = d1.alloc(n * sizeof(double))) return rc; H2D(d1.p, par1, n * sizeof(double)); }
+    DevBuf dtab;
+    {
+        std::vector<double> tab((size_t)PG_NBIN * 4);
+        for (int k = 0; k < PG_NBIN; ++k) pg_bin(k, &tab[(size_t)4 * k]);
+        if (int rc = dtab.alloc(tab.size() * sizeof(double))) return rc;
+        H2D(dtab.p, tab.data(), tab.size() * sizeof(double));
+    }
     const int bt = 256; const int gb = (int)((n + bt - 1) / bt);
     if (precision == ERM_PREC_F32)
-        hipLaunchKernelGGL((sample_batch_kernel<float>), dim3(gb), dim3(bt), 0, 0, which, seed, site, sweep, (long long)n, d0.as<double>(), d1.as<double>(), dout.as<double>());
+        hipLaunchKernelGGL((sample_batch_kernel<float>), dim3(gb), dim3(bt), 0, 0, which, seed, site, sweep, (long long)n, d0.as<double>(), d1.as<double>(), dout.as<double>(), dtab.as<double>());
     else
-        hipLaunchKernelGGL((sample_batch_kernel<double>), dim3(gb), dim3(bt), 0, 0, which, seed, site, sweep, (long long)n, d0.as<double>(), d1.as<double>(), dout.as<double>());
+        hipLaunchKernelGGL((sample_batch_kernel<double>), dim3(gb), dim3(bt), 0, 0, which, seed, site, sweep, (long long)n, d0.as<double>(), d1.as<double>(), dout.as<double>(), dtab.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));

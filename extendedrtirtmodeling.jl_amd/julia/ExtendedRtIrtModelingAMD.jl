@@ -30,7 +30,7 @@ struct ErmConfig
     model::Int32; n_item::Int32; n_subj::Int64; n_feat::Int32; n_iter::Int32; n_chain::Int32; n_burnin::Int32
     intercept::Int32; one_pl::Int32; cov2one::Int32; sigp_mode::Int32; chain_id::Int32; q_rt::Float64; seed::UInt64
     device::Int32; precision::Int32; trace_mode::Int32; lanes_per_row::Int32; block_threads::Int32; grid_blocks::Int32
-    profile::Int32; reserved::Int32
+    profile::Int32; flags::Int32; nu_trace_max_gb::Float64
 end
 struct ErmState
     theta::Ptr{Float64}; a::Ptr{Float64}; b::Ptr{Float64}; zeta::Ptr{Float64}; lambda::Ptr{Float64}; sig2t::Ptr{Float64}
@@ -123,7 +123,7 @@ function engine!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool; uploa
     M.handle != C_NULL && ccall((:erm_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), M.handle)
     C = M.Cond
     cfg = ErmConfig(modelid(M), C.nItem, C.nSubj, C.nFeat, C.nIter, C.nChain, C.nBurnin, intercept, onepl, cov2one, 0, 0, C.qRt,
-                    M.seed, M.device, M.precision, 1, 0, 0, 0, 0, 0)
+                    M.seed, M.device, M.precision, 1, 0, 0, 0, 0, 0, 0.0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:erm_create, LIB[]), Cint, (Ref{ErmConfig}, Ref{Ptr{Cvoid}}), cfg, h))
     if M.shard !== nothing       # one chain over several devices (include/ertirt.h, erm_set_shard_rccl): collective, before the data
@@ -155,7 +155,7 @@ function sampleFarm!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool, d
     M.shard === nothing || error("a subject-sharded sampler cannot also farm chains")
     devs = Int32[devices[mod1(l, length(devices))] for l in 1:C.nChain]
     cfg = ErmConfig(modelid(M), C.nItem, C.nSubj, C.nFeat, C.nIter, 1, C.nBurnin, intercept, onepl, cov2one, 0, 0, C.qRt,
-                    M.seed, 0, M.precision, 1, 0, 0, 0, 0, 0)
+                    M.seed, 0, M.precision, 1, 0, 0, 0, 0, 0, 0.0)
     f = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:erm_farm_create, LIB[]), Cint, (Ref{ErmConfig}, Ptr{Int32}, Int32, Ref{Ptr{Cvoid}}), cfg, devs, C.nChain, f))
     try

@@ -60,9 +60,16 @@ typedef struct {
     int32_t lanes_per_row;  /* 0 = auto; power of two in [1,64]: lanes that share one subject */
     int32_t block_threads;  /* 0 = auto */
     int32_t grid_blocks;    /* 0 = auto */
-    int32_t profile;        /* 1 = bracket every 8th sweep's row-pass launch with HIP events (erm_get_timing) */
-    int32_t reserved;
+    int32_t profile;        /* 1 = bracket sweep-kernel launches with HIP events for erm_get_timing: two single sweeps before every replayed 32-sweep block of a
+                             * long run; every sweep (in replayed 16- / 4-sweep graphs) of a run shorter than 68 sweeps */
+    int32_t flags;          /* ERM_FLAG_* (diagnostics; none changes a result) */
+    double  nu_trace_max_gb; /* GibbsRtIrtCrossQr, ERM_TRACE_FULL: budget in GiB for the per-sweep vec(nu) block of Post.qr (0 = the default, 16) */
 } erm_config;
+enum {
+    ERM_FLAG_NO_FUSE = 1,          /* two kernels per sweep (stand-alone tiny step + row pass) instead of the fused sweep kernel */
+    ERM_FLAG_NO_GRAPH = 2,         /* enqueue every sweep instead of replaying the captured 32-sweep hipGraph */
+    ERM_FLAG_FARM_FORCE_RCCL = 4   /* erm_farm_get_mean reduces over RCCL even when all chains share one device (one-rank communicator; tests) */
+};
 
 /* Mirrors InputPara (src/Base.pl.jl:100-115).  NULL members are skipped.  Shapes:
  * theta,zeta [nSubj]; a,b,lambda,sig2t,rho [nItem]; sigp [4] = vec(Sigma_p);
@@ -112,7 +119,7 @@ int erm_reset_trace(erm_handle h);   /* forget recorded rows and running means (
 
 /* Post.ra / Post.rt / Post.qr / Post.logLike (src/GibbsRtIrt.pl.jl:35-71; Cross :55-69; Latent :50-64) in Julia layout
  * [nIter][width][nChain], nIter fastest.  Needs ERM_TRACE_FULL for RA/RT/QR.  GibbsRtIrtCrossQr's qr carries vec(nu) (nSubj*nItem values per
- * sweep); it is recorded when nIter*nChain*nSubj*nItem values fit ERM_NU_TRACE_MAX_GB (environment, default 16), else ERM_ERR_NOTRACE. */
+ * sweep); it is recorded when nIter*nChain*nSubj*nItem values fit erm_config.nu_trace_max_gb (default 16 GiB), else ERM_ERR_NOTRACE. */
 int64_t erm_trace_width(erm_handle h, int which);
 int erm_get_trace(erm_handle h, int which, double* out);
 /* item-level trace, always kept: out[row][4*nItem + nq] = a, b, lambda, sig2t, small part of qr (row-major) */
@@ -160,7 +167,7 @@ int erm_copy(void* dst, const void* src, size_t bytes);
  * cfg->n_chain are ignored (every chain records cfg->n_iter rows).  One host thread per chain inside the library drives that chain's
  * stream, so the chains sample concurrently and never communicate.  erm_farm_get_mean is the only collective: the post-burn-in sums
  * of the chains on one device are added on that device, the devices' vectors are summed by ONE ncclAllReduce (RCCL over xGMI, bound at
- * run time as for erm_set_shard_rccl; skipped when all chains share one device unless ERM_FARM_FORCE_RCCL is set) and divided by the
+ * run time as for erm_set_shard_rccl; skipped when all chains share one device unless ERM_FLAG_FARM_FORCE_RCCL is set) and divided by the
  * total number of post-burn-in rows.  Deliberate deviation from the reference: its nChain > 1 is ONE chain whose sweeps are dealt
  * round-robin to nChain trace slabs (erm_create with n_chain > 1 reproduces that); independent chains leave Post.mean unchanged in
  * expectation and make R-hat meaningful.
@@ -180,6 +187,14 @@ int erm_farm_get_trace(erm_farm_handle f, int which, double* out);
 int erm_farm_get_mean(erm_farm_handle f, erm_state* out);
 int64_t erm_farm_post_count(erm_farm_handle f);
 int erm_farm_used_rccl(erm_farm_handle f);                  /* 1 if the last erm_farm_get_mean reduced over RCCL */
+/* What a multi-GPU benchmark of the farm reports: wall-clock of the last erm_farm_run (all chains, host side), the device time of each chain's
+ * last erm_run (run_ms[n_chains], may be NULL), the wall-clock of the last erm_farm_get_mean and of its all-reduce alone, and the number of ranks
+ * of the library's own RCCL communicator (ncclCommCount; 0 if no communicator exists). */
+typedef struct {
+    double run_wall_ms, gather_ms, allreduce_ms;
+    int32_t rccl_ranks, n_devices;
+} erm_farm_timing;
+int erm_farm_get_timing(erm_farm_handle f, erm_farm_timing* out, double* run_ms);
 
 const char* erm_last_error(void);
 const char* erm_version(void);

@@ -147,24 +147,48 @@ static inline double orc_ndtri(double p)
 
 /* ---- Polya-Gamma PG(1, c): Devroye / Polson-Scott-Windle sampler for J*(1, z = |c|/2), t = 0.64, restated as a
  * SINGLE-LEVEL rejection sampler in which one attempt consumes exactly one Philox block (u0..u3) and has no inner loop.
- * Target (unnormalised): f(x) = e^{-z^2 x/2} sum_n (-1)^n a_n(x), a_n as in PSW (2013).  Envelope, three pieces:
- *   x > t          : a_0(x) e^{-z^2 x/2} = (pi/2) e^{-K x},           K = pi^2/8 + z^2/2, mass p = pi/(2K) e^{-K t}
- *   x <= t, z < 1/t: a_0(x)            (the Levy / inverse-chi^2_1 kernel), mass q0 = 4 Phi(-1/sqrt t); the factor
- *                    e^{-z^2 x/2} <= 1 is applied as an acceptance probability
- *   x <= t, z >= 1/t: a_0(x) e^{-z^2 x/2} extended to ALL x > 0 (the IG(1/z, 1) kernel), mass 2 e^{-z}; draws with
- *                    x > t are rejected
- * so the tail is proposed with probability r = p / (p + q_env), q_env = q0 or 2 e^{-z} -- closed form, no normal cdf.
- *   u0 < r : X = t + (-log u1)/K
- *   else, z < 1/t : X = 1/Z^2, Z = -Phi^-1(u1 Phi(-1/sqrt t)) (> 1/sqrt t); reject the attempt if u2 > e^{-z^2 X/2}
- *   else          : X ~ IG(1/z, 1) by Michael-Schucany-Haas with N = Phi^-1(u1), root choice u2; reject if X > t
- *   then the alternating-series test with V = u3 in ratio form S_n/a_0 = 1 - rho_1 + rho_2 - ...,
- *        rho_n = a_n/a_0 = (2n+1) e^{-pi^2 n(n+1) X/2} (X > t)  or  (2n+1) e^{-2 n(n+1)/X} (X <= t).
- * Same law as PolyaGammaPSWSampler(1, eta) (src/Draw.pl.jl:38): PG(1,c) = J*(1,|c|/2)/4. */
+ * Target (unnormalised): f(x) = e^{-z^2 x/2} sum_n (-1)^n a_n(x), a_n as in PSW (2013).  Envelope, two pieces per z:
+ *   x > t  : a_0(x) e^{-z^2 x/2} = (pi/2) e^{-K x},  K = pi^2/8 + z^2/2, mass p = pi/(2K) e^{-K t}; proposal X = t + E/K, E = -log u1.
+ *   x <= t : a_0(x) e^{-z^2 x/2} = 4 phi(Z) e^{-z^2/(2 Z^2)} dZ in terms of Z = x^{-1/2} >= a = 1/sqrt(t)  (a_0 is twice the Levy density,
+ *            i.e. X = 1/Z^2 with Z a half-normal).  Two proposals:
+ *     z < 8  : Robert's (1995) exponential proposal for a normal tail, tilted per z:  Z = a + E/lam, E = -log u1.  With
+ *              g(Z) = -(Z - lam)^2/2 - z^2/(2 Z^2):   4 phi(Z) e^{-z^2/(2Z^2)} = [4/(lam sqrt(2 pi)) e^{lam^2/2 - lam a + M}] . lam e^{-lam (Z-a)} . e^{g(Z) - M},
+ *              so for any M >= max_{Z >= a} g the bracket is the piece's envelope mass q and e^{g(Z) - M} <= 1 the acceptance probability.
+ *              g is concave in Z and decreasing in z.  (lam, M) come from a table over z-bins of width 1/16: for the bin with lower edge z_k,
+ *              Z*^2 = sqrt(10.6 + 1.07 z_k^2) (a fit of the mass-minimising choice), d = z_k^2 / Z*^3, lam = Z* - d (=> g'(Z*; z_k) = 0),
+ *              M = g(Z*; z_k) = -d^2/2 - z_k^2/(2 Z*^2): exact maximum for z = z_k, an upper bound for every z in the bin.
+ *              One logarithm serves both pieces; no normal quantile, no inner loop.  Acceptance of the whole attempt before the series
+ *              test: 0.95 at z = 0, 0.92 at z = 1, 0.80 at z = 2, 0.65 at z = 3, 0.27 at z = 8.
+ *     z >= 8 : a_0(x) e^{-z^2 x/2} extended to ALL x > 0 (the IG(1/z, 1) kernel), mass 2 e^{-z}; X ~ IG(1/z, 1) by Michael-Schucany-Haas
+ *              with N = Phi^-1(u1), root choice u2; draws with X > t are rejected (|eta| >= 16: rare; acceptance -> 1).
+ *   The tail is proposed with probability r = p / (p + q).  Then the alternating-series test with V = u3 in ratio form
+ *   S_n/a_0 = 1 - rho_1 + rho_2 - ..., rho_n = a_n/a_0 = (2n+1) e^{-pi^2 n(n+1) X/2} (X > t)  or  (2n+1) e^{-2 n(n+1)/X} (X <= t).
+ * Same law as PolyaGammaPSWSampler(1, eta) (src/Draw.pl.jl:38): PG(1,c) = J*(1,|c|/2)/4 -- tests/test_oracle_psw.py compares the draws
+ * with an independently written two-level PSW/Devroye sampler. */
 #define ORC_PG_T 0.64
-#define ORC_PG_Q0 0.42259909466742100 /* 4 Phi(-1/sqrt(t)) = 4 Phi(-1.25) */
-#define ORC_PG_PHI_M 0.10564977366685525 /* Phi(-1.25) */
+#define ORC_PG_A 1.25            /* 1/sqrt(t) */
+#define ORC_PG_NBIN 128
+#define ORC_PG_ZMAX 8.0          /* NBIN bins of width 1/16 */
 
 static inline double orc_u32_to_unif(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
+
+/* left-piece proposal parameters of z-bin k: rate lam, c = 1/lam, bound M, envelope mass q */
+static inline void orc_pg_bin(int k, double* lam, double* c, double* M, double* q)
+{
+    double zk = (double)k / 16.0;
+    double Zs2 = sqrt(10.6 + 1.07 * zk * zk), Zs = sqrt(Zs2);
+    double d = zk * zk / (Zs * Zs2);
+    double l = Zs - d, m = -0.5 * d * d - 0.5 * zk * zk / Zs2;
+    *lam = l; *c = 1.0 / l; *M = m;
+    *q = 4.0 / (l * sqrt(2.0 * ORC_PI)) * exp(0.5 * l * l - ORC_PG_A * l + m);
+}
+
+/* envelope mass of the left piece at z */
+static inline double orc_pg_left_mass(double z)
+{
+    if (z < ORC_PG_ZMAX) { double lam, c, M, q; orc_pg_bin((int)(z * 16.0), &lam, &c, &M, &q); return q; }
+    return 2.0 * exp(-z);
+}
 
 /* probability that an attempt proposes from the exponential tail */
 static inline double orc_pg_tail_weight(double z)
@@ -172,8 +196,7 @@ static inline double orc_pg_tail_weight(double z)
     const double t = ORC_PG_T;
     double K = 0.125 * ORC_PI * ORC_PI + 0.5 * z * z;
     double p = ORC_PI / (2.0 * K) * exp(-K * t);
-    double qenv = (z < 1.5625) ? ORC_PG_Q0 : 2.0 * exp(-z); /* 1/t */
-    return p / (p + qenv);
+    return p / (p + orc_pg_left_mass(z));
 }
 
 /* one attempt; returns 1 and sets *out = X/4 on acceptance */
@@ -186,10 +209,12 @@ static inline int orc_pg1_attempt(double z, const uint32_t w[4], double* out)
     double x;
     if (u0 < r) {
         x = t + (-log(u1)) / K;
-    } else if (z < 1.5625) {
-        double zt = -orc_ndtri(u1 * ORC_PG_PHI_M);
-        x = 1.0 / (zt * zt);
-        if (u2 > exp(-0.5 * z * z * x)) return 0;
+    } else if (z < ORC_PG_ZMAX) {
+        double lam, c, M, q;
+        orc_pg_bin((int)(z * 16.0), &lam, &c, &M, &q);
+        double Z = ORC_PG_A + c * (-log(u1));
+        x = 1.0 / (Z * Z);
+        if (u2 > exp(-0.5 * (Z - lam) * (Z - lam) - 0.5 * z * z * x - M)) return 0;
     } else {
         double mu = 1.0 / z, n = orc_ndtri(u1);
         double ww = mu * n * n;

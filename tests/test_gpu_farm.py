@@ -1,6 +1,6 @@
 """Chain farm behind the C ABI (erm_farm_*, include/ertirt.h): nChain independent chains, one per device slot, sampled concurrently by
 host threads of the library, Post.mean reduced on the device(s).  On the one-GPU test box every chain sits on device 0; the RCCL
-all-reduce is exercised with a one-device communicator (ERM_FARM_FORCE_RCCL=1)."""
+all-reduce is exercised with a one-device communicator (erm_config.flags = ERM_FLAG_FARM_FORCE_RCCL)."""
 import numpy as np
 import pytest
 
@@ -26,16 +26,14 @@ def _separate(model, Y, logT, X, inits, T, precision, qRt=0.85):
 
 @pytest.mark.parametrize("model", ["rtirt", "mlirt", "latentqr", "crossqr"])
 @pytest.mark.parametrize("force_rccl", [False, True])
-def test_farm_equals_separate_engines(model, force_rccl, monkeypatch):
-    if force_rccl:
-        monkeypatch.setenv("ERM_FARM_FORCE_RCCL", "1")
+def test_farm_equals_separate_engines(model, force_rccl):
     L = pu.ge.load_package()._lib
     N, J, T, nch = 600, 8, 12, 3
     Y, logT, X, init, _ = pu.make_problem(model, N, J)
     g = np.random.default_rng(5)
     inits = [dict(init, theta=g.standard_normal(N)) for _ in range(nch)]
     farm = L.Farm([0] * nch, model=pu.MODELS[model], n_item=J, n_subj=N, n_feat=0 if X is None else X.shape[1], n_iter=T, n_chain=1, n_burnin=T // 2,
-                  cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, precision=1, trace_mode=1)
+                  cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, precision=1, trace_mode=1, flags=L.FLAG_FARM_FORCE_RCCL if force_rccl else 0)
     farm.set_data(Y, logT, X)
     for l in range(nch):
         farm.set_state(l, **{("lambda_" if k == "lam" else k): v for k, v in inits[l].items()})
@@ -50,6 +48,9 @@ def test_farm_equals_separate_engines(model, force_rccl, monkeypatch):
     # Post.mean = joint mean over iterations and chains = count-weighted mean of the separate engines' means (to rounding)
     fm = farm.get_mean()
     assert farm.post_count == sum(e.post_count for e in engs) and farm.used_rccl == force_rccl
+    tm = farm.timing()          # erm_farm_get_timing: what bench.py --gpus N reports
+    assert tm["rccl_ranks"] == (1 if force_rccl else 0) and tm["n_devices"] == 1 and tm["run_wall_ms"] > 0 and tm["gather_ms"] > 0 and np.all(tm["run_ms"] > 0)
+    assert (tm["allreduce_ms"] > 0) == force_rccl
     means = [e.get_mean() for e in engs]
     for k, v in fm.items():
         if v is None:

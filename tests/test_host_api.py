@@ -22,12 +22,28 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.erm_version()
 
 
-def test_ctypes_struct_layout_matches_header():
-    # field order and sizes of erm_config / erm_timing as declared in include/ertirt.h
-    assert C.sizeof(pkg._lib.erm_config) == 4 * 2 + 8 + 4 * 9 + 4 + 8 + 8 + 4 * 8     # 108 -> padded
-    assert pkg._lib.erm_config.n_subj.offset == 8 and pkg._lib.erm_config.q_rt.offset == 56 and pkg._lib.erm_config.seed.offset == 64
-    assert C.sizeof(pkg._lib.erm_state) == 10 * C.sizeof(C.c_void_p)
-    assert C.sizeof(pkg._lib.erm_timing) == 8 * 5 + 4 * 6
+def test_ctypes_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of every struct of include/ertirt.h as gcc lays them out, against the ctypes mirrors field by field."""
+    import subprocess
+    L = pkg._lib
+    structs = {"erm_config": L.erm_config, "erm_state": L.erm_state, "erm_timing": L.erm_timing, "erm_farm_timing": L.erm_farm_timing}
+    alias = {"lambda_": "lambda"}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "ertirt.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        src.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for f, _ in cls._fields_:
+            src.append(f'  printf("{name}.{f} %zu\\n", offsetof({name}, {alias.get(f, f)}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(pu.ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert C.sizeof(cls) == int(got[name]), name
+        for f, _ in cls._fields_:
+            assert getattr(cls, f).offset == int(got[f"{name}.{f}"]), (name, f)
+    assert C.sizeof(L.erm_config) == 112 and L.erm_config.q_rt.offset == 56 and L.erm_config.nu_trace_max_gb.offset == 104
 
 
 def test_create_without_gpu_reports_an_error_instead_of_falling_back():

@@ -13,8 +13,6 @@ N, J, T, nch = 600, 8, 12, 3
 bad = 0
 for bt in bts:
     for force in ("0", "1"):
-        os.environ["ERM_FARM_FORCE_RCCL"] = force
-        if force == "0": os.environ.pop("ERM_FARM_FORCE_RCCL")
         for model in ("rtirt", "mlirt", "latentqr", "crossqr"):
             if model == "latentqr" and bt > 768: continue
             Y, logT, X, init, _ = pu.make_problem(model, N, J)
@@ -22,10 +20,11 @@ for bt in bts:
             inits = [dict(init, theta=g.standard_normal(N)) for _ in range(nch)]
             kw = dict(model=pu.MODELS[model], n_item=J, n_subj=N, n_feat=0 if X is None else X.shape[1], n_iter=T, n_chain=1, n_burnin=T // 2,
                       cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, precision=1, trace_mode=1, block_threads=bt)
+            fkw = dict(kw, flags=L.FLAG_FARM_FORCE_RCCL if force == "1" else 0)
             ref = [None] * nch
             nsep = nfarm = 0
             for r in range(reps):
-                farm = L.Farm([0] * nch, **kw); farm.set_data(Y, logT, X)
+                farm = L.Farm([0] * nch, **fkw); farm.set_data(Y, logT, X)
                 for l in range(nch): farm.set_state(l, **{("lambda_" if k == "lam" else k): v for k, v in inits[l].items()})
                 farm.run(T)
                 ft = farm.trace(L.TRACE_RA)
