@@ -44,6 +44,7 @@ template <typename real> struct PassArgs {
     int skew;             // FUSED kernels: subjects taken off wave 0's slice (it runs the structural chain of the tiny step first)
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // -DERM_DIAG_BUILD only: skip everything after stage k (0 = run everything); ignored by the shipped library
+    uint32_t dbg_sweep;   // -DERM_DIAG_BUILD only: 0 = the stop applies to every launch, else only to the launch that draws this sweep
     unsigned long long* dbg_ts;   // diagnostics only (ERM_TIMELINE): [2 workgroups][16 waves][16 checkpoints] of the 100 MHz wall clock
     int acc_off;          // byte offset in dynamic LDS of the per-wave item accumulators [nWaves][NSTAT][J], the LAST region of a launch's LDS
     uint32_t row_base;    // subject index of local row 0 in the whole data set (subject-sharded chains; 0 otherwise): the random streams are
@@ -61,7 +62,7 @@ __device__ __forceinline__ void wave_sync()
 
 template <typename real> __device__ __forceinline__ real row_normal(uint32_t wa, uint32_t wb, [[maybe_unused]] const double2* tab = nullptr)
 {
-    if constexpr (sizeof(real) == 8) return fm::sqrt(-2.0 * (tab ? fm::log(word_to_unif<double>(wa), tab) : fm::log(word_to_unif<double>(wa)))) * cospi(2.0 * word_to_unif<double>(wb));
+    if constexpr (sizeof(real) == 8) return fm::sqrt(-2.0 * (tab ? fm::log(word_to_unif<double>(wa), tab) : fm::log(word_to_unif<double>(wa)))) * fm::cos2pi(word_to_unif<double>(wb));
     else return r_sqrt(real(-2) * r_log(word_to_unif<real>(wa))) * r_cos2pi(word_to_unif<real>(wb));
 }
 
@@ -81,7 +82,9 @@ constexpr int KB = 4;     // items per lane whose loads are in flight together i
 // Stage-timing / counting diagnostics (early returns that leave GARBAGE results, PG attempt counters) exist only in a library built with
 // -DERM_DIAG_BUILD (tools/tiny_stages.sh); the shipped library has no such code path, so no environment variable can corrupt a fit.
 #ifdef ERM_DIAG_BUILD
-#define ERM_DIAG_STOP(args, k) do { if ((args).dbg_stop == (k)) return; } while (0)
+// (with dbg_sweep != 0 the early return applies to that ONE sweep only: every launch before it ran in full, so the truncated launch works on a valid
+// chain state -- tools/stage_budget.sh reads its counters and its duration)
+#define ERM_DIAG_STOP(args, k) do { if ((args).dbg_stop == (k) && ((args).dbg_sweep == 0u || sweep == (args).dbg_sweep)) return; } while (0)
 #define ERM_DIAG_ON(args, k) ((args).dbg_stop == (k))
 #else
 #define ERM_DIAG_STOP(args, k) ((void)0)
@@ -122,6 +125,7 @@ struct TinyArgs {
     int nq;               // number of small qr entries recorded per sweep
     int ngx;              // extra global statistics of slab0 (see PassArgs::ngx)
     int dbg_stop;         // -DERM_DIAG_BUILD only: return after stage k (0 = run everything); ignored by the shipped library
+    uint32_t dbg_sweep;   // -DERM_DIAG_BUILD only: see PassArgs::dbg_sweep
 };
 
 __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
@@ -603,11 +607,8 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
 {
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
-#ifndef ERM_SHAREDQ
-#define ERM_SHAREDQ 2
-#endif
-    // ONE cell queue per workgroup in the PG phase instead of one per wave (1: fp64 engine, 2: both engines, 0: off)
-    constexpr bool SHQ = PHASE == 0 && (ERM_SHAREDQ == 2 || (ERM_SHAREDQ == 1 && sizeof(real) == 8));
+    // the PG phase hands the workgroup's cells out from ONE dynamic queue (round 2: one queue per wave made the waves of a SIMD finish up to
+    // 50 us apart -- the hardware favours a SIMD's oldest wave)
     const int J = A.J, W = A.W, R = 64 / W, IPL = A.IPL;
     const int F = A.nFeat, p = F + 1;                // design [1 X]
     const int NG = ST::ng(p) + A.ngx;
@@ -622,8 +623,8 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
     real* sh_item = reinterpret_cast<real*>(sh_gacc + (size_t)nWaves * NG);    // [NITEMARR][J]
     real* sh_a = sh_item, *sh_b = sh_item + J, *sh_a2 = sh_item + 2 * J, *sh_a2b = sh_item + 3 * J;
     real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
-    real* sh_th = sh_item + NITEMARR * J + (size_t)wave * 4 * A.rows_per_wave;   // theta_t of this wave's subjects
-    real* sh_rs = sh_th + A.rows_per_wave;                                         // [rows_per_wave][3] row sums
+    real* sh_rs = sh_item + NITEMARR * J;                                          // [rows_per_block][3] row sums, indexed by the subject's position in the workgroup
+                                                                                   // (the region holds nWaves * 4 * rows_per_wave >= 4 * rows_per_block values)
     const int NV = A.nFeat + 4;
     real* sh_val = sh_item + NITEMARR * J + (size_t)nWaves * 4 * A.rows_per_wave;   // [rows_per_block][NV] per-subject values of the global statistics
 
@@ -686,9 +687,9 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         reduce_rows(T.slab0, T.nb0, NS0, st0, tid, nthr);
         __syncthreads();
         stamp(1);
-        ERM_DIAG_STOP(A, 30);
         const uint32_t prev_row = T.ctl->row;
         sweep = T.ctl->sweep + 1u;
+        ERM_DIAG_STOP(A, 30);
         trow = T.first ? prev_row : prev_row + 1u;
         if (writer && tid == 0 && !T.first && T.tr_ll) T.tr_ll[prev_row] = st0[NS0 - 1];    // log-likelihood of the sweep the last pass completed
         // item draws now; the structural chain (beta_t -> Sigma_p_t, ~7 us of dependent fp64 work on one wave) runs on wave 0 AFTER the
@@ -828,7 +829,7 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
             }
             s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W);
             if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
-            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - ra); o[0] = s0; o[1] = s1; o[2] = s2; }
+            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - row0); o[0] = s0; o[1] = s1; o[2] = s2; }
         }
     } else if (A.mode == 1) {
         for (long long g0 = ra; g0 < rb; g0 += R) {
@@ -869,20 +870,20 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
             }
             s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W);
             if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
-            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - ra); o[0] = s0; o[1] = s1; o[2] = s2; }
+            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - row0); o[0] = s0; o[1] = s1; o[2] = s2; }
         }
     }
-    wave_sync();
+    // every wave's row sums (and, FUSED, wave 0's structural results in sh_struct: it stored them before its own row sums) are visible to
+    // the whole workgroup from here on
+    __syncthreads();
     stamp(4);
     ERM_DIAG_STOP(A, 5);
 
     // =================================================================================================== phase 1 (ii)
-    // one lane per subject: theta_t / zeta_t draws, per-subject outputs, structural log-likelihood, LatentQr's nu_{t+1}
-    if constexpr (FUSED) {
-        // wave 0 finished the structural chain long before any wave gets here (it takes less time than the row sums); the wait is a guard
-        while (__hip_atomic_load(sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
+    // one lane per subject: theta_t / zeta_t draws, per-subject outputs, structural log-likelihood, LatentQr's nu_{t+1}.  The workgroup's
+    // subjects are dealt to consecutive lanes of the WORKGROUP (subject q of the block on lane q mod 64 of wave q / 64), not of the wave that
+    // summed them: a wave's own slice is ~24 subjects, i.e. sixteen waves each paid a whole trip of this ~300-instruction phase with a third of
+    // their lanes -- issue-bound, 7.2 us of the fp64 sweep; packed, seven waves make the trip and the others go straight to the next barrier.
     stamp(5);
     const real sig11 = (MODEL == MLIRT) ? real(1) : (real)sh_struct[0];
     const real sig22 = (real)sh_struct[3];
@@ -890,12 +891,13 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
     const double* beta = sh_struct + 8;
     // bivariate-normal log-density constants of Sigma_p (src/GibbsRtIrt.pl.jl:268-269)
     const double sp_det = sh_struct[0] * sh_struct[3] - sh_struct[1] * sh_struct[2];
-    const double sp_c0 = -LOG_2PI - 0.5 * log(sp_det);
-    const double sp_q00 = sh_struct[3] / sp_det, sp_q01 = -(sh_struct[1] + sh_struct[2]) / sp_det, sp_q11 = sh_struct[0] / sp_det;
-    for (long long ib = ra; ib < rb; ib += 64) {
-        const bool rok = ib + lane < rb;
-        const long long i = rok ? ib + lane : ra;          // clamped: loads are unconditional, stores masked
-        const int li = (int)(i - ra);
+    const double sp_idet = q_rcp(sp_det);
+    const double sp_c0 = -LOG_2PI - 0.5 * q_log(sp_det);
+    const double sp_q00 = sh_struct[3] * sp_idet, sp_q01 = -(sh_struct[1] + sh_struct[2]) * sp_idet, sp_q11 = sh_struct[0] * sp_idet;
+    for (int q0 = (int)threadIdx.x & ~63; q0 < nrows_blk; q0 += (int)blockDim.x) {
+        const bool rok = q0 + lane < nrows_blk;
+        const long long i = row0 + (rok ? q0 + lane : 0);  // clamped: loads are unconditional, stores masked
+        const int li = (int)(i - row0);
         real th = A.theta[i];
         real ze = (MODEL != MLIRT) ? A.zeta[i] : real(0);
         real nu_row = real(1);
@@ -930,9 +932,9 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
             if (PHASE == 0) {
                 // theta: src/Draw.pl.jl:49-62 (prior x*beta[:,1]) / :67-80 (Null prior)
                 const real mu0 = (MODEL == MLIRT || MODEL == RTIRT) ? mu0a : real(0);
-                const real parV = r_rcp(r_rcp(sig11) + sA);
-                const real parM = parV * (r_div(mu0, sig11) + sB);
-                th = parM + r_sqrt(parV) * row_normal<real>(rw0, rw1, logtab);
+                const real parV = q_rcp(q_rcp(sig11) + sA);
+                const real parM = parV * (q_div(mu0, sig11) + sB);
+                th = parM + q_sqrt(parV) * row_normal<real>(rw0, rw1, logtab);
             }
             if (fam_rt(MODEL) || fam_lq(MODEL)) {
                 // zeta: src/Draw.pl.jl:132-141 / :161-174 (LatentQr) / :147-156 (Latent) / :119-127 (Null: prior N(0,1), Sigp unused)
@@ -943,15 +945,15 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                     mu0 = xb5 + k1 * nu_row;
                     s0 = sig22 * (k2 * nu_row);
                 }
-                const real parV = r_rcp(r_rcp(s0) + sum_isig);
-                const real parM = parV * (r_div(mu0, s0) + sC);
-                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3, logtab);
+                const real parV = q_rcp(q_rcp(s0) + sum_isig);
+                const real parM = parV * (q_div(mu0, s0) + sC);
+                ze = parM + q_sqrt(parV) * row_normal<real>(rw2, rw3, logtab);
             }
             if (fam_cq(MODEL) && PHASE == 1) {
                 // zeta: src/Draw.pl.jl:192-206 (CrossQr) / :179-187 (Cross) (zero prior mean, prior variance Sigp[2,2]); sA = sum of weights here
-                const real parV = r_rcp(r_rcp(sig22) + sA);
+                const real parV = q_rcp(q_rcp(sig22) + sA);
                 const real parM = parV * sC;
-                ze = parM + r_sqrt(parV) * row_normal<real>(rw2, rw3, logtab);
+                ze = parM + q_sqrt(parV) * row_normal<real>(rw2, rw3, logtab);
             }
             if (rok) {
                 if (PHASE == 0) {
@@ -974,7 +976,7 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                 } else if (fam_lq(MODEL)) {
                     const double var = (double)sig22 * ((double)k2 * (double)nu_row);
                     const double e = (double)(ze - (xb5 + k1 * nu_row));
-                    ll += -0.5 * LOG_2PI - 0.5 * log(var) - 0.5 * e * e / var;
+                    ll += -0.5 * LOG_2PI - 0.5 * q_log(var) - 0.5 * q_div(e * e, var);
                     if (MODEL == LATENTQR) {
                         if (A.tr_nu) A.tr_nu[(size_t)trow * A.N + i] = nu_row;
                         if (post_burn) A.sum_nu[i] += (double)nu_row;
@@ -993,12 +995,11 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
             nu_next = qr_weight<real>(st, parA, parB, logtab);
             if (rok) A.nu[i] = nu_next;
         }
-        if (PHASE == 0 && rok) sh_th[li] = th;
 
         // ---- per-subject values of the global statistics (sums over subjects of products of two of them), parked in LDS and reduced
         // by the whole workgroup after the barrier below (a 64-lane fp64 butterfly per statistic here cost 6 us of the pass):
         // slot c-1 holds value code c: 1..F -> X columns, F+1 theta, F+2 zeta, F+3 u = zeta - k1 nu_{t+1}, F+4 nu_{t+1}
-        if ((NG > 1 || SHQ) && rok) {
+        if ((NG > 1 || PHASE == 0) && rok) {
             real* o = sh_val + (size_t)(i - row0) * NV;
             for (int u = 1; u <= F; ++u) o[u - 1] = xcol(u);
             o[F] = th; o[F + 1] = ze; o[F + 2] = ze - k1 * nu_next; o[F + 3] = nu_next;
@@ -1013,24 +1014,22 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
     // to its next cell as soon as a draw is accepted, so a wave pays the max over lanes of the TOTAL attempts of ~equal queues.
     // Attempt k of cell (i, j) uses Philox block k of stream (OMEGA, i, j, sweep+1).
     if constexpr (PHASE == 0) {
-        wave_sync();                                  // sh_th written above
-        if constexpr (SHQ) { if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(sh_struct + 6) = blockDim.x; __syncthreads(); }
-        const long long qrow0 = SHQ ? row0 : ra;      // first subject of the queue's slice
-        const int ncell = (SHQ ? nrows_blk : (int)(rb - ra)) * J;
-        auto theta_of = [&](int rr_) -> real { if constexpr (SHQ) return sh_val[(size_t)rr_ * NV + F]; else return sh_th[rr_]; };
+        if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(sh_struct + 6) = blockDim.x;
+        __syncthreads();                              // theta_t of every subject of the workgroup is parked in sh_val
+        const long long qrow0 = row0;                 // first subject of the queue's slice
+        const int ncell = nrows_blk * J;
+        auto theta_of = [&](int rr_) -> real { return sh_val[(size_t)rr_ * NV + F]; };
         const float invJ = 1.0f / (float)J;
-        // cells are handed out dynamically from a wave-shared LDS counter: a lane that finishes a cell grabs the next index, so
+        // cells are handed out dynamically from a workgroup-shared LDS counter: a lane that finishes a cell grabs the next index, so
         // every lane stays busy until the slice is exhausted (which lane draws which cell does not matter: draws are addressed
         // by (i, j, sweep), never by lane)
-        unsigned int* qhead = SHQ ? reinterpret_cast<unsigned int*>(sh_struct + 6) : reinterpret_cast<unsigned int*>(sh_rs);      // the row sums are dead by now
-        if (!SHQ && lane == 0) *qhead = 64u;
-        wave_sync();
+        unsigned int* qhead = reinterpret_cast<unsigned int*>(sh_struct + 6);
         auto locate = [&](int c, int& rr, int& j) {      // c -> (row within slice, item); exact for c < 2^22
             rr = (int)(((float)c + 0.5f) * invJ);
             j = c - rr * J;
             if (j < 0) { j += J; --rr; } else if (j >= J) { j -= J; ++rr; }
         };
-        int c = SHQ ? (int)threadIdx.x : lane, rr, j;
+        int c = (int)threadIdx.x, rr, j;
         locate(c, rr, j);
         bool active = c < ncell;
         uint32_t att = 0;

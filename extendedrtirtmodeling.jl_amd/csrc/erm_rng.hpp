@@ -141,6 +141,17 @@ __device__ __forceinline__ double exp_neg(double a)
 }
 }  // namespace fm
 
+// "quick" forms for operands known to be normal, finite (and positive where a root or logarithm is taken): fp32 = the hardware-rate instruction,
+// fp64 = the range-specialised forms above (<= 1 ulp) instead of the IEEE division (30 instructions), OCML's sqrt (22), log (98) and cospi (66)
+__device__ __forceinline__ float  q_rcp(float x)  { return r_rcp(x); }
+__device__ __forceinline__ double q_rcp(double x) { return fm::rcp(x); }
+__device__ __forceinline__ float  q_div(float a, float b)  { return r_div(a, b); }
+__device__ __forceinline__ double q_div(double a, double b) { return fm::div(a, b); }
+__device__ __forceinline__ float  q_sqrt(float x)  { return r_sqrt(x); }
+__device__ __forceinline__ double q_sqrt(double x) { return fm::sqrt(x); }
+__device__ __forceinline__ float  q_log(float x)  { return r_log(x); }
+__device__ __forceinline__ double q_log(double x) { return fm::log(x); }
+
 template <typename real> struct Const;
 template <> struct Const<float> {
     static constexpr float PI = 3.14159265358979323846f;

@@ -396,7 +396,7 @@ template <typename real> struct Engine : EngineBase {
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
         if (!m_nu()) { a.k1 = 0.0; a.k2 = 1.0; }                                   // no quantile weights: nu == 1, k1 = 0, k2 = 1
-        a.dbg_stop = diag_stop("ERM_PASS_STOP");
+        a.dbg_stop = diag_stop("ERM_PASS_STOP"); a.dbg_sweep = (uint32_t)diag_stop("ERM_STOP_SWEEP");
         a.dbg_ts = dDbgTs.as<unsigned long long>();
         a.row_base = (uint32_t)row_base;
         a.acc_off = fz ? G.acc_off_fused : G.acc_off[phase];     // the accumulators close the launch's dynamic LDS
@@ -419,7 +419,7 @@ template <typename real> struct Engine : EngineBase {
         if (sharded()) {     // the statistics rows of all devices, gathered after every row pass; N = the whole data set
             t.slab0 = dShardRecv[0].as<double>(); t.slab1 = dShardRecv[1].as<double>(); t.nb0 = shard_count; t.nb1 = shard_count; t.N = n_total;
         }
-        t.dbg_stop = diag_stop("ERM_TINY_STOP");
+        t.dbg_stop = diag_stop("ERM_TINY_STOP"); t.dbg_sweep = (uint32_t)diag_stop("ERM_STOP_SWEEP");
         return t;
     }
 

@@ -56,6 +56,108 @@ def test_fullsize_other_models_run_clean(model):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
+# fp64 (the product default, the bench headline) at PRODUCTION geometry for every kernel instantiation.  Each model is its own template
+# instantiation of pass_kernel<MODEL, double, ...> (LatentQr is even compiled for a different workgroup size); the small-data rule of the planner
+# shrinks workgroups to 256 threads below ~6 000 subjects, so only sizes like these exercise the 1024-thread (768 for LatentQr) kernels the
+# BASELINE.md numbers come from.  Reference loops: /root/reference/src/GibbsRtIrt.pl.jl:210-257 (MlIrt), :367-426 (Null),
+# src/GibbsRtIrtLatent.pl.jl:271-337 (LatentQr), :168-233 (Latent), src/GibbsRtIrtCross.pl.jl:265-325 (CrossQr), :176-235 (Cross).
+# ------------------------------------------------------------------------------------------------------------------------------
+OTHERS = ["mlirt", "latentqr", "crossqr", "null", "cross", "latent"]
+
+
+def _oracle_sweeps(model, Y, logT, X, init, T, qRt):
+    pu.oracle().orc_set_threads(16)                      # OpenMP mode: bit-identical to the single-thread run (test_oracle_sweeps.py)
+    try:
+        op = pu.OracleProblem(model, Y, logT, X, init, qRt=qRt, cov2one=(model not in ("latentqr", "latent")))
+        return op, op.run(T, with_nu=(model in ("latentqr", "crossqr")))
+    finally:
+        pu.oracle().orc_set_threads(1)
+
+
+def _assert_traces(model, dev, tr, tol=1e-8):
+    """Every trace column of every sweep within `tol` -- except GibbsRtIrtCrossQr's sweeps after the first: its chain is chaotic (the 1/nu
+    weights pin zeta_i to its smallest-nu residual, a 1 ulp difference grows to 1e-2 within 12 sweeps), and over 100 000 subjects the largest
+    deviation of sweep 2 already reaches ~5e-8; sweep 1 is held to `tol`, later free-running sweeps to 1e-6, and the model is checked
+    teacher-forced besides (test_fullsize_f64_crossqr_teacher_forced_sweep)."""
+    rows = dev["ra"].shape[0]
+    tols = np.array([tol if (model != "crossqr" or t == 0) else 1e-6 for t in range(rows)])[:, None]
+    assert np.all(pu.rel_err(dev["ra"][:, :, 0], tr["ra"]) < tols)
+    if model != "mlirt":
+        assert np.all(pu.rel_err(dev["rt"][:, :, 0], tr["rt"]) < tols)
+    assert np.all(pu.rel_err(dev["qr"][:, :, 0], tr["qr"]) < tols)          # LatentQr: every nu_i; CrossQr: every nu_ij (5e6 per sweep)
+    assert np.all(pu.rel_err(dev["ll"][:, 0, 0], tr["ll"]) < 0.1 * tols[:, 0])
+
+
+@pytest.mark.parametrize("model", OTHERS)
+def test_fullsize_f64_every_model_matches_oracle_at_production_geometry(model):
+    """100 000 x 50, qRt = 0.85, default geometry, fp64: two free-running sweeps elementwise against the oracle (CrossQr including every nu), then
+    bit-reproducibility and run(a) + run(b) == run(a + b)."""
+    Y, logT, X, init, _ = pu.make_problem(model, N, J, 3, seed=77, qRt=0.85)
+    dev = pu.run_device(model, Y, logT, X, init, 2, precision="f64", qRt=0.85, n_burnin=0)
+    tm = dev["engine"].timing()
+    assert tm["block_threads"] == (768 if model == "latentqr" else 1024) and tm["grid_blocks"] == tm["cu_count"]       # one full-size workgroup per CU
+    _, tr = _oracle_sweeps(model, Y, logT, X, init, 2, 0.85)
+    _assert_traces(model, dev, tr)
+    del dev
+    T = 7
+    a = pu.run_device(model, Y, logT, X, init, T, precision="f64", qRt=0.85, trace_full=False)
+    b = pu.run_device(model, Y, logT, X, init, T, precision="f64", qRt=0.85, trace_full=False)
+    assert np.array_equal(a["item"], b["item"]) and np.array_equal(a["ll"], b["ll"])
+    assert np.all(np.isfinite(a["item"])) and np.all(np.isfinite(a["ll"]))
+    L = pu.ge.load_package()._lib
+    eng = L.Engine(model=pu.MODELS[model], n_item=J, n_subj=N, n_feat=0 if X is None else 3, n_iter=T, n_chain=1, n_burnin=T // 2,
+                   cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, precision=1, trace_mode=0)
+    eng.set_data(Y, logT, X)
+    eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in init.items()})
+    for n in (3, 1, 3):
+        eng.run(n)
+    assert np.array_equal(eng.item_trace(), a["item"]) and np.array_equal(eng.trace(L.TRACE_LOGLIKE), a["ll"])
+    ma, me = a["engine"].get_mean(), eng.get_mean()
+    for k in ("theta", "zeta", "nu"):
+        if ma[k] is not None:
+            assert np.array_equal(ma[k], me[k]), k
+
+
+def test_fullsize_f64_crossqr_teacher_forced_sweep():
+    """GibbsRtIrtCrossQr is chaotic (1 ulp -> 1e-2 within 12 sweeps), so beyond its free-running sweeps it is checked teacher-forced:
+    sweep 3 started from the ORACLE's state after sweep 2, every conditional on a realistic chain state at full size."""
+    model = "crossqr"
+    Y, logT, X, init, _ = pu.make_problem(model, N, J, 3, seed=78, qRt=0.85)
+    op, _ = _oracle_sweeps(model, Y, logT, X, init, 2, 0.85)
+    L = pu.ge.load_package()._lib
+    names = dict(theta="theta", a="a", b="b", zeta="zeta", lambda_="lambda_", sig2t="sig2t", sigp="Sigp", rho="rho", nu="nu")
+    # the oracle's sweep counter stands at 2: the device must draw sweep 3's variates -- its own counter is advanced by two throw-away sweeps first
+    eng2 = L.Engine(model=pu.MODELS[model], n_item=J, n_subj=N, n_feat=0, n_iter=3, n_chain=1, n_burnin=0, cov2one=1, q_rt=0.85, seed=1234, precision=1, trace_mode=0)
+    eng2.set_data(Y, logT, X)
+    eng2.set_state(**{("lambda_" if k == "lam" else k): v for k, v in init.items()})
+    eng2.run(2)
+    st = {k: op.arr[v].copy() for k, v in names.items()}
+    eng2.set_state(**st)
+    eng2.run(1)
+    pu.oracle().orc_set_threads(16)
+    try:
+        op.run(1)
+    finally:
+        pu.oracle().orc_set_threads(1)
+    dev = eng2.get_state()
+    for k, v in names.items():
+        if k == "nu":
+            continue               # the device's nu is already the next sweep's draw (fused schedule)
+        assert pu.rel_err(dev[k], op.arr[v], 1e-6).max() < 1e-8, k
+
+
+@pytest.mark.parametrize("model", ["rtirt"] + OTHERS)
+def test_midsize_f64_one_sweep_matches_oracle_in_full_size_workgroups(model):
+    """30 000 x 50: still one 1024-thread (768) workgroup per CU, a third of the subjects per wave -- another point of the same kernels."""
+    n = 30_000
+    Y, logT, X, init, _ = pu.make_problem(model, n, J, 3, seed=79, qRt=0.85)
+    dev = pu.run_device(model, Y, logT, X, init, 1, precision="f64", qRt=0.85, n_burnin=0)
+    assert dev["engine"].timing()["block_threads"] == (768 if model == "latentqr" else 1024)
+    _, tr = _oracle_sweeps(model, Y, logT, X, init, 1, 0.85)
+    _assert_traces(model, dev, tr)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[4]: GibbsRtIrt nSubj = 500000, nItem = 100 (one chain's load on one GPU).  The working set (Y 50 MB, logT and
 # omega 200 / 400 MB each) no longer fits the 256 MiB Infinity Cache, a workgroup owns ~1950 subjects x 100 items and the LDS layout
 # grows with nItem -- a regime of its own for the engine.
