@@ -9,11 +9,15 @@ Headline = the fp64 engine (`dtype: f64`): the reference's arithmetic is Float64
 The fp32 fast mode (fp32 cell arithmetic, fp64 accumulation) is measured in the same invocation on the same resident inputs and
 carried in the same JSON line as the nested object `fp32`.
 
-N GPUs = N independent chains (one process per GPU, chain_id = rank, no data-path collective): "scaling": "weak".
-`python bench.py --gpus N` creates its N ranks itself when it is not already running under torch.distributed.run: the parent --
-which never touches HIP or torch -- starts N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and relays rank 0's line.
-After the timed region the ranks all-reduce their posterior summaries over RCCL (timed separately, reported as gather_ms).
-At N > 1 the line also carries `configs4`: the same measurement on BASELINE.json configs[4]'s per-GPU load (500000 x 100).
+N GPUs = N independent chains, one per GPU, no data-path collective: "scaling": "weak".  What is measured at N > 1 is the path a Julia
+`sample!(MCMC; devices = 0:N-1)` binds: the library's own chain farm behind the C ABI (erm_farm_create / set_data / run / get_mean: ONE process, one
+host thread per chain inside the library, the posterior summaries reduced by the library's own RCCL communicator -- ncclCommInitAll over the N
+devices, one ncclAllReduce; `rccl_ranks` is that communicator's ncclCommCount, `gather_ms` the erm_farm_get_mean time).  `python bench.py --gpus N`
+runs it directly; under `torch.distributed.run --nproc-per-node N` (the driver's launch) rank 0 drives the farm over the N devices and the other ranks
+only take part in the barriers and the MAX-reduction of the time (torch.distributed over gloo: they never touch a GPU).  `--multiprocess` keeps the
+older layout (one process per GPU, torch.distributed "nccl", chain_id = rank; `python bench.py --gpus N --multiprocess` spawns its ranks itself).
+At N > 1 the line also carries BASELINE.json configs[4] (500000 x 100, nChain = N, one chain per GPU) as `configs4_value` / `configs4_ms_per_step`
+and the nested object `configs4`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (the fused sweep kernel): algorithmic bytes per launch / mean launch duration measured live with
@@ -24,6 +28,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -65,6 +70,8 @@ def parse_args(argv=None):
                                                         "host callback over torch.distributed")
     ap.add_argument("--shard", action="store_true", help="NOT the headline: ONE chain of --nsubj subjects sharded over the ranks (strong scaling; "
                                                         "one all-gather of a statistics row per row pass, SURVEY.md 8(e))")
+    ap.add_argument("--multiprocess", action="store_true", help="N > 1: one process per GPU over torch.distributed instead of the library's in-process chain farm")
+    ap.add_argument("--no-cold", action="store_true", help="skip the extra cold measurement (the same W + K steps from an idle device, before the clock warm-up)")
     return ap.parse_args(argv)
 
 
@@ -85,8 +92,28 @@ def spawn_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+    # rank 0's output is collected by a reader thread while every child is polled: a rank that dies before or at the rendezvous must not leave
+    # the others (and this parent) waiting for torch's own time-out
+    import threading
+    import time as _time
+    chunks = []
+    th = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        _time.sleep(0.1)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    th.join(timeout=30)
+    out = "".join(c or "" for c in chunks)
+    rcs = [p.returncode for p in procs]
     line = None
     for ln in (out or "").splitlines():
         if ln.startswith('{"metric"'):
@@ -217,16 +244,29 @@ def measure(pkg, ge_mod, torch, dist, args, model, N, J, F, precision, data, st,
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        eng.run(args.warmup)
+    # 1. cold: the W warm-up steps and K timed steps from an idle device -- what `--warmup W` alone produces (reported as ms_per_step_cold)
+    dt_cold = None
+    if not args.no_cold and args.clock_warmup_ms > 0:
+        if args.warmup > 0:
+            eng.run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        eng.run(args.steps)
+        barrier()
+        dt_cold = time.perf_counter() - t0
+        eng.reset_trace()
+    # 2. untimed clock warm-up: the chain simply continues (its trace rows are recycled) until the device has been busy for --clock-warmup-ms
     spun = 0
-    if args.clock_warmup_ms > 0:        # untimed: the chain simply continues (its trace rows are recycled), so the timed steps start from a busy device
+    if args.clock_warmup_ms > 0:
         t_end = time.perf_counter() + args.clock_warmup_ms * 1e-3
         while time.perf_counter() < t_end:
             eng.reset_trace()
             eng.run(min(rows, 64))
             spun += min(rows, 64)
         eng.reset_trace()
+    # 3. the W warm-up steps (= the burn-in rows), then EXACTLY K timed steps, all of them post-burn-in
+    if args.warmup > 0:
+        eng.run(args.warmup)
     barrier()
     t0 = time.perf_counter()
     eng.run(args.steps)            # erm_run returns after hipStreamSynchronize on the engine's stream
@@ -235,10 +275,81 @@ def measure(pkg, ge_mod, torch, dist, args, model, N, J, F, precision, data, st,
     tm = eng.timing()
     tm["clock_warmup_sweeps"] = spun
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        t = torch.tensor([dt, dt_cold if dt_cold is not None else 0.0], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        dt_cold = float(t[1].item()) if dt_cold is not None else None
+    tm["dt_cold"] = dt_cold
     return dt, tm, eng, n_loc
+
+
+def measure_farm(pkg, torch, dist, args, model, N, J, F, precision, data, n_dev, devices, trace, flags=0, truth=None, rank=0):
+    """The N > 1 measurement: the library's chain farm (erm_farm_*), driven by THIS process -- chain l on device devices[l], one host thread per
+    chain inside the library.  Ranks other than 0 (under torch.distributed.run) only join the barriers.  Returns (dt, dt_cold, farm timing dict,
+    chain 0's engine timing, farm) on the driving rank, (dt, dt_cold, None, None, None) elsewhere."""
+    rows = args.warmup + args.steps
+    driver = rank == 0
+    L = pkg._lib if driver else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if driver and torch.cuda.is_available():      # the other ranks have no GPU work (and never create a context)
+            for d in sorted(set(devices)):
+                torch.cuda.synchronize(d)
+
+    farm = None
+    if driver:
+        farm = L.Farm(devices, model=getattr(L, "MODEL_" + model.upper()), n_item=J, n_subj=N, n_feat=F if model not in ("crossqr", "cross") else 0, n_iter=rows, n_chain=1,
+                      n_burnin=args.warmup, cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, precision=L.PREC_F32 if precision == "f32" else L.PREC_F64,
+                      trace_mode=L.TRACE_FULL if trace == "full" else L.TRACE_SUMMARY, lanes_per_row=args.lanes_per_row, block_threads=args.block_threads,
+                      grid_blocks=args.grid_blocks, profile=0 if args.no_profile else 1, flags=flags)
+        if truth is not None:      # generated ON each device from the same data seed: every chain sees the same data set
+            for l in range(n_dev):
+                farm.engine(l).simulate_data(seed=1234, **truth)
+        else:
+            farm.set_data(*data)   # inputs resident in HBM from here on (every chain its own copy, uploaded by the chain's host thread)
+        for l in range(n_dev):     # every chain its own setInitialValues
+            farm.set_state(l, **{("lambda_" if k == "lam" else k): v for k, v in init_state(model, N, J, F, l).items()})
+    dt_cold = None
+    if not args.no_cold and args.clock_warmup_ms > 0:
+        if driver and args.warmup > 0:
+            farm.run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        if driver:
+            farm.run(args.steps)
+        barrier()
+        dt_cold = time.perf_counter() - t0
+        if driver:
+            farm.reset_trace()
+    spun = 0
+    if driver and args.clock_warmup_ms > 0:
+        t_end = time.perf_counter() + args.clock_warmup_ms * 1e-3
+        while time.perf_counter() < t_end:
+            farm.reset_trace()
+            farm.run(min(rows, 64))
+            spun += min(rows, 64)
+        farm.reset_trace()
+    if driver and args.warmup > 0:
+        farm.run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    if driver:
+        farm.run(args.steps)       # erm_farm_run returns when every chain's stream has been synchronised
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, dt_cold if dt_cold is not None else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0].item())
+        dt_cold = float(t[1].item()) if dt_cold is not None else None
+    if not driver:
+        return dt, dt_cold, None, None, None
+    ftm = farm.timing()
+    ftm["clock_warmup_sweeps"] = spun
+    etm = farm.engine(0).timing()
+    return dt, dt_cold, ftm, etm, farm
 
 
 def roofline(model, N, J, n_loc, precision, tm):
@@ -261,9 +372,125 @@ def roofline(model, N, J, n_loc, precision, tm):
     return out
 
 
+def main_farm(args, world_env):
+    """`--gpus N` (N > 1): the library's chain farm.  One driving process (rank 0, or the only process); see the module docstring."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(world_env or "1")
+    n_dev = args.gpus
+    if world_env is not None and world != n_dev:
+        raise SystemExit(f"bench.py: --gpus {n_dev} but WORLD_SIZE={world}")
+    rehearse = os.environ.get("ERM_BENCH_REHEARSE") == "1"      # the N > 1 path on a ONE-GPU box: every chain on device 0, the reduction over a one-rank RCCL communicator
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))       # barriers and one MAX only: the data path has no torch collective
+    if os.environ.get("ERM_BENCH_LAUNCH_ONLY") == "1":
+        tot = None
+        if dist is not None:
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(t)
+            tot = float(t.item())
+        if rank == 0:
+            print(json.dumps({"metric": "launcher self-test", "mode": "farm", "n_gpus": n_dev, "ranks": world, "rank_sum": tot, "backend": "gloo" if dist is not None else None,
+                              "steps": args.steps}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    driver = rank == 0
+    pkg = L = None
+    data = None
+    model, N, J, F = args.model, args.nsubj, args.nitem, args.nfeat
+    prec = args.precision
+    devices = [0] * n_dev if rehearse else list(range(n_dev))
+    flags = 0
+    if driver:
+        import __graft_entry__ as ge
+        ge.build_hip()
+        pkg = ge.load_package()
+        L = pkg._lib
+        data = make_data(pkg, model, N, J, F, seed=1234)
+        flags = L.FLAG_FARM_FORCE_RCCL if rehearse else 0
+    common = dict(pkg=pkg, torch=torch, dist=dist, args=args, n_dev=n_dev, devices=devices, flags=flags, rank=rank)
+    dt, dt_cold, ftm, etm, farm = measure_farm(model=model, N=N, J=J, F=F, precision=prec, data=data, trace=args.trace, **common)
+    gather = None
+    if driver:      # Post.mean over iterations and chains: the ONE collective of the path (the library's RCCL all-reduce)
+        farm.get_mean()
+        g = farm.timing()
+        gather = {"gather_ms": g["gather_ms"], "allreduce_ms": g["allreduce_ms"], "rccl_ranks": g["rccl_ranks"], "n_devices": g["n_devices"], "used_rccl": farm.used_rccl,
+                  "post_count": farm.post_count}
+        del farm
+    fp32 = None
+    if prec == "f64" and not args.no_fp32:
+        dt32, _, _, etm32, farm32 = measure_farm(model=model, N=N, J=J, F=F, precision="f32", data=data, trace=args.trace, **common)
+        if driver:
+            del farm32
+            fp32 = {"value": float(N) * J * args.steps * n_dev / dt32, "unit": "cell-updates/s", "ms_per_step": dt32 / args.steps * 1e3, "dtype": "f32",
+                    "note": "fp32 cell arithmetic, fp64 accumulation and item-level draws; same workload, steps and warm-up", "roofline": roofline(model, N, J, N, "f32", etm32)}
+    # BASELINE.json configs[4]: GibbsRtIrt 500000 x 100, nChain = N, one chain per GPU
+    cfg4 = None
+    if not args.no_configs4 and model == "rtirt" and (N, J) != (500000, 100):
+        N4, J4 = (20000, 100) if rehearse else (500000, 100)
+        a4 = argparse.Namespace(**vars(args))
+        a4.steps, a4.warmup = min(args.steps, 100), min(args.warmup, 10)
+        truth4 = None
+        if driver:  # 5e7 cells per chain: generated on the device from setTrueParaRtIrt's item / structural truth
+            tp4 = pkg.setTrueParaRtIrt(pkg.setCond(nSubj=N4, nItem=J4, nFeat=F, nIter=10, nChain=1), seed=np.random.default_rng(1234))
+            truth4 = dict(a=tp4.a, b=tp4.b, lambda_=tp4.lam, sig2t=tp4.sig2t, sigp=np.asarray(tp4.Sigp, dtype=np.float64).reshape(-1, order="F"),
+                          beta=np.asarray(tp4.beta, dtype=np.float64).reshape(-1, order="F"))
+        dt4, dt4c, ftm4, etm4, farm4 = measure_farm(model=model, N=N4, J=J4, F=F, precision=prec, data=None, trace="summary", truth=truth4, **dict(common, args=a4))
+        if driver:
+            farm4.get_mean()
+            g4 = farm4.timing()
+            del farm4
+            cfg4 = {"workload": f"GibbsRtIrt nSubj={N4} nItem={J4} nFeat={F} nChain={n_dev}, one chain per GPU (BASELINE.json configs[4]), summary traces",
+                    "data": "synthetic, generated on the device (erm_simulate_data)", "value": float(N4) * J4 * a4.steps * n_dev / dt4, "unit": "cell-updates/s",
+                    "ms_per_step": dt4 / a4.steps * 1e3, "ms_per_step_cold": None if dt4c is None else dt4c / a4.steps * 1e3, "steps": a4.steps, "warmup": a4.warmup, "dtype": prec,
+                    "per_chain_device_ms_per_step": [float(v) / a4.steps for v in ftm4["run_ms"]], "gather_ms": g4["gather_ms"], "allreduce_ms": g4["allreduce_ms"],
+                    "roofline": roofline(model, N4, J4, N4, prec, etm4)}
+    if driver:
+        cells = float(N) * J
+        out = {
+            "metric": "Gibbs cell-updates/s (nSubj x nItem x sweeps/s)", "value": cells * args.steps * n_dev / dt, "unit": "cell-updates/s",
+            "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": f"Gibbs{NAMES[model]} nSubj={N} nItem={J} nFeat={F} nChain={n_dev}, one chain per GPU (BASELINE.json configs[2] per GPU)",
+                       "path": "erm_farm_create / set_data / set_state / run / get_mean (the C-ABI chain farm: one process, one host thread per chain inside the library)",
+                       "chains": n_dev, "devices": devices, "subject_shards": 1, "trace": args.trace, "lanes_per_row": etm["lanes_per_row"], "block_threads": etm["block_threads"],
+                       "grid_blocks": etm["grid_blocks"], "lds_bytes": etm["lds_bytes"], "ranks": world,
+                       "collective_backend": "RCCL inside libertirt.so (ncclCommInitAll over the farm's devices, one ncclAllReduce in erm_farm_get_mean)"
+                                             + ("; torch.distributed gloo for the launcher's barriers only" if dist is not None else ""),
+                       "rccl_ranks": gather["rccl_ranks"]},
+            "sweeps_per_s": args.steps * n_dev / dt, "farm_run_wall_ms_per_step": ftm["run_wall_ms"] / args.steps,
+            "per_chain_device_ms_per_step": [float(v) / args.steps for v in ftm["run_ms"]],
+            "gather_ms": gather["gather_ms"], "allreduce_ms": gather["allreduce_ms"], "gather": gather,
+            "untimed_clock_warmup": {"ms": args.clock_warmup_ms, "sweeps": ftm["clock_warmup_sweeps"],
+                                     "note": "untimed sweeps of the same chains BEFORE the W warm-up steps; ms_per_step_cold is the same W + K steps without them"},
+        }
+        if dt_cold is not None:
+            out["ms_per_step_cold"] = dt_cold / args.steps * 1e3
+        rf = roofline(model, N, J, N, prec, etm)
+        if rf is not None:
+            out["roofline"] = dict(rf, note="chain 0's sweep kernel (every chain runs the same kernel on its own device)")
+        if fp32 is not None:
+            out["fp32"] = fp32
+        if cfg4 is not None:
+            out["configs4_value"], out["configs4_ms_per_step"], out["configs4"] = cfg4["value"], cfg4["ms_per_step"], cfg4
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and not args.multiprocess and not args.shard:
+        return main_farm(args, world_env)
     if args.gpus > 1 and world_env is None:
         # not under torch.distributed.run: make the ranks ourselves (nothing GPU-related has been imported in this process)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -278,6 +505,8 @@ def main():
     world = int(world_env or "1")
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("ERM_BENCH_DIE_RANK") == str(rank):      # launcher self-test: this rank dies before the rendezvous
+        raise SystemExit(3)
     rehearse = os.environ.get("ERM_BENCH_REHEARSE") == "1"
     import torch
     dist = None
@@ -289,11 +518,11 @@ def main():
         if rehearse:     # ERM_BENCH_REHEARSE=1: the N>1 code path on a ONE-GPU box -- every rank on cuda:0, collectives over gloo on the CPU
             local_rank = 0
             backend = "gloo"
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         else:
             backend = "nccl"
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
         assert dist.get_world_size() == world
 
     if os.environ.get("ERM_BENCH_LAUNCH_ONLY") == "1":
@@ -375,8 +604,12 @@ def main():
                        "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"], "ranks": world, "collective_backend": backend,
                        "rccl_ranks": world if backend == "nccl" else 0},
             "sweeps_per_s": args.steps * (1 if shard else world) / dt, "device_ms_per_step": tm["run_ms"] / args.steps,
-            "untimed_clock_warmup": {"ms": args.clock_warmup_ms, "sweeps": tm["clock_warmup_sweeps"], "note": "further untimed sweeps of the same chain between the W warm-up steps and the timed region"},
+            "untimed_clock_warmup": {"ms": args.clock_warmup_ms, "sweeps": tm["clock_warmup_sweeps"],
+                                     "note": "untimed sweeps of the same chain BEFORE the W warm-up steps (a few ms of work do not bring an idle MI355X to its sustained clock); "
+                                             "ms_per_step_cold is the same W + K steps without them"},
         }
+        if tm.get("dt_cold") is not None:
+            out["ms_per_step_cold"] = tm["dt_cold"] / args.steps * 1e3
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
         rf = roofline(model, N, J, n_loc, prec, tm)
