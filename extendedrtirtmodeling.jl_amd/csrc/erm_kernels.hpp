@@ -130,9 +130,9 @@ struct TinyArgs {
 
 __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
 {
-    const double d1 = 1.0 / sqrt(S[0]);
+    const double d1 = q_rcp(q_sqrt(S[0]));
     S[0] *= d1 * d1; S[1] *= d1; S[2] *= d1;
-    const double d2 = 1.0 / sqrt(S[3]);
+    const double d2 = q_rcp(q_sqrt(S[3]));
     S[3] *= d2 * d2; S[1] *= d2; S[2] *= d2;
     S[0] = 1.0; S[3] = 1.0;
 }
@@ -192,7 +192,7 @@ __device__ inline double beta_normal(uint64_t seed, uint32_t chain, uint32_t swe
     uint32_t w0, w1, w2, w3;
     philox4x32_10(0u, 0u, sweep, ((uint32_t)SITE_BETA << 24) | ((chain & 0xFFu) << 16) | (uint32_t)(i >> 1), (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
     const double u1 = word_to_unif<double>((i & 1) ? w2 : w0), u2 = word_to_unif<double>((i & 1) ? w3 : w1);
-    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+    return q_sqrt(-2.0 * q_log(u1)) * q_cos2pi(u2);
 }
 
 
@@ -231,9 +231,9 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
         Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
         if (fam_rt(MODEL)) {
             const double df = Nd + 3.0;
-            spd[0] = sqrt(chisq(ss, df));
+            spd[0] = q_sqrt(chisq(ss, df));
             spd[1] = normal<double>(ss);
-            spd[2] = sqrt(chisq(ss, df - 1.0));
+            spd[2] = q_sqrt(chisq(ss, df - 1.0));
         } else {
             spd[0] = gamma_mt(ss, 1e-3 + (MODEL == LATENTQR ? Nd * 3.0 / 2.0 : Nd / 2.0));
         }
@@ -253,23 +253,24 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
                 // rho_t: drawSubjCorrCrossQr src/Draw.pl.jl:474-489 / drawSubjCorrCross :463-469 (uses sig2t_{t-1})
                 const double sg = par[3 * J + j];
                 const double R0 = st1[0 * J + j], R1 = st1[1 * J + j];
-                const double parV = 1.0 / (1.0 + R0 / (sg * T.k2));
-                const double parM = parV * (0.0 + R1 / (sg * T.k2));
+                const double isk = q_rcp(sg * T.k2);
+                const double parV = q_rcp(1.0 + R0 * isk);
+                const double parM = parV * (0.0 + R1 * isk);
                 Stream sr(T.seed, T.chain, SITE_RHO, 0u, (uint32_t)j, sweep);
-                par[4 * J + j] = parM + sqrt(parV) * normal<double>(sr);
+                par[4 * J + j] = parM + q_sqrt(parV) * normal<double>(sr);
             }
             auto draw_b = [&]() {   // drawItemDifficulty src/Draw.pl.jl:98-105
-                const double parV = 1.0 / (1.0 + a * a * S0);
+                const double parV = q_rcp(1.0 + a * a * S0);
                 const double parM = parV * (0.0 - (a * K0[j] - a * a * S1));
                 Stream sb(T.seed, T.chain, SITE_B, 0u, (uint32_t)j, sweep);
-                double v = parM + sqrt(parV) * normal<double>(sb);
+                double v = parM + q_sqrt(parV) * normal<double>(sb);
                 b = v < -4.0 ? -4.0 : (v > 4.0 ? 4.0 : v);
             };
             auto draw_a = [&]() {   // drawItemDiscrimination src/Draw.pl.jl:88-93
-                const double parV = 1.0 / (1.0 + (S2 - 2.0 * b * S1 + b * b * S0));
+                const double parV = q_rcp(1.0 + (S2 - 2.0 * b * S1 + b * b * S0));
                 const double parM = parV * (1.0 + (K1 - b * K0[j]));
                 Stream sa(T.seed, T.chain, SITE_A, 0u, (uint32_t)j, sweep);
-                a = truncnorm0(sa, parM, sqrt(parV));
+                a = truncnorm0(sa, parM, q_sqrt(parV));
                 if (T.onepl) a = 1.0;
             };
             if (MODEL == MLIRT) { draw_a(); draw_b(); }   // src/GibbsRtIrt.pl.jl:233-237
@@ -285,33 +286,35 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
             const double zz = fam_rt(MODEL) ? G0[2 * p + 2] : G0[2 * p + 6];
             const double Gj = st0[4 * J + j];
             const double sg_old = par[3 * J + j];
-            const double parV = 1.0 / (1.0 / (sdLam * sdLam) + Nd / sg_old);
-            const double parM = parV * (muLam / (sdLam * sdLam) + (Nd * cm[j] + sz) / sg_old);
+            const double isd2 = q_rcp(sdLam * sdLam), isg = q_rcp(sg_old);
+            const double parV = q_rcp(isd2 + Nd * isg);
+            const double parM = parV * (muLam * isd2 + (Nd * cm[j] + sz) * isg);
             Stream sl(T.seed, T.chain, SITE_LAMBDA, 0u, (uint32_t)j, sweep);
-            const double lam = truncnorm0(sl, parM, sqrt(parV));
+            const double lam = truncnorm0(sl, parM, q_sqrt(parV));
             const double lc = lam - cm[j];
             const double ssq = csq[j] + 2.0 * Gj + zz - 2.0 * lc * sz + Nd * lc * lc;
             Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
             const double sg = invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq / 2.0);
             par[2 * J + j] = lam; par[3 * J + j] = sg;
-            part[j] = 1.0 / sg;
+            part[j] = q_rcp(sg);
         }
         if (fam_cq(MODEL) && STEP == 1) {
             // lambda: drawItemIntensityCrossQr src/Draw.pl.jl:239-251 / ...Cross :225-231 ; sig2t: drawItemTimeResidualCrossQr :278-288 / ...Cross :267-273
             const double W0 = st0[4 * J + j], W1 = st0[5 * J + j], W2 = st0[6 * J + j], V = st0[7 * J + j];
             const double sg_old = par[3 * J + j];
-            const double parV = 1.0 / (1.0 / (sdLam * sdLam) + W0 / (sg_old * T.k2));
-            const double parM = parV * (muLam / (sdLam * sdLam) + (W1 + cm[j] * W0) / (sg_old * T.k2));
+            const double isd2 = q_rcp(sdLam * sdLam), isk = q_rcp(sg_old * T.k2);
+            const double parV = q_rcp(isd2 + W0 * isk);
+            const double parM = parV * (muLam * isd2 + (W1 + cm[j] * W0) * isk);
             Stream sl(T.seed, T.chain, SITE_LAMBDA, 0u, (uint32_t)j, sweep);
-            const double lam = truncnorm0(sl, parM, sqrt(parV));
+            const double lam = truncnorm0(sl, parM, q_sqrt(parV));
             const double lc = lam - cm[j];
             const double ssq = (W2 - 2.0 * lc * W1 + lc * lc * W0) / (2.0 * T.k2);
             Stream sv(T.seed, T.chain, SITE_SIG2T, 0u, (uint32_t)j, sweep);
             const double sg = (MODEL == CROSSQR) ? invgamma(sv, 1e-3 + Nd * 3.0 / 2.0, 1e-3 + ssq + V) : invgamma(sv, 1e-3 + Nd / 2.0, 1e-3 + ssq);
             par[2 * J + j] = lam; par[3 * J + j] = sg;
-            part[j] = 1.0 / sg;
+            part[j] = q_rcp(sg);
         }
-        if (MODEL == MLIRT || (fam_cq(MODEL) && STEP == 0)) part[j] = 1.0 / par[3 * J + j];   // sig2t not drawn in this step
+        if (MODEL == MLIRT || (fam_cq(MODEL) && STEP == 0)) part[j] = q_rcp(par[3 * J + j]);   // sig2t not drawn in this step
     }
 }
 
@@ -349,8 +352,8 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             const double* xt = G0, *xz = G0 + p;
             if (PART != 1) {
             const double s00 = Sigp[0], s10 = Sigp[1], s01 = Sigp[2], s11 = Sigp[3];
-            const double sdet = s00 * s11 - s10 * s01;
-            const double iO[4] = { s11 / sdet, -s10 / sdet, -s01 / sdet, s00 / sdet };
+            const double isdet = q_rcp(s00 * s11 - s10 * s01);
+            const double iO[4] = { s11 * isdet, -s10 * isdet, -s01 * isdet, s00 * isdet };
             if (lane < p) { double t = 0.0; for (int w = 0; w < p; ++w) t += Xinv[lane + w * PMAX]; rs[lane] = t; }
             wave_sync();
             if (lane < n) {
@@ -361,11 +364,12 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             wave_sync();
             double cden = 1.0;
             for (int i = 0; i < n; ++i) cden += vv[i];
+            const double icden = q_rcp(cden);
             for (int e = lane; e < n * n; e += 64) {
                 int i = e % n, jj = e / n;
                 if (i > jj) { const int t_ = i; i = jj; jj = t_; }              // Symmetric(parV): upper triangle
                 const int a_ = i / p, u = i % p, b_ = jj / p, w = jj % p;
-                V[e] = Sigp[a_ + 2 * b_] * Xinv[u + w * PMAX] - vv[i] * vv[jj] / cden;
+                V[e] = Sigp[a_ + 2 * b_] * Xinv[u + w * PMAX] - vv[i] * vv[jj] * icden;
             }
             wave_sync();
             double pm = 0.0;
@@ -403,7 +407,7 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             const int q = p + 1;
             double* Mx = work, *L = Mx + q * q, *V = L + q * q, *tv = V + q * q;
             const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1; const double tz = G0[2 * p + 1];
-            const double iO = 1.0 / Sigp[3];
+            const double iO = q_rcp(Sigp[3]);
             if (PART != 1) {
             for (int e = lane; e < q * q; e += 64) {
                 const int i = e % q, jj = e / q;
@@ -418,12 +422,12 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
                 for (int i = 0; i < q; ++i) {
                     double t = (i == k) ? 1.0 : 0.0;
                     for (int m = 0; m < i; ++m) t -= L[i + m * q] * V[m + k * q];
-                    V[i + k * q] = t / L[i + i * q];
+                    V[i + k * q] = q_div(t, L[i + i * q]);
                 }
                 for (int i = q - 1; i >= 0; --i) {
                     double t = V[i + k * q];
                     for (int m = i + 1; m < q; ++m) t -= L[m + i * q] * V[m + k * q];
-                    V[i + k * q] = t / L[i + i * q];
+                    V[i + k * q] = q_div(t, L[i + i * q]);
                 }
             }
             wave_sync();
@@ -463,7 +467,7 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
                     h[u] = t1; g[u] = t2;
                 }
                 for (int u = 0; u < p; ++u) { hx += xt[u] * h[u]; hu += h[u] * xu[u]; }
-                const double b2 = (tu - hu) / (tt - hx);
+                const double b2 = q_div(tu - hu, tt - hx);
                 for (int u = 0; u < p; ++u) bn[u] = g[u] - h[u] * b2;
                 bn[p] = b2;
                 if (!T.intercept) bn[0] = 0.0;                                   // src/GibbsRtIrtLatent.pl.jl:288-290
@@ -493,14 +497,14 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
             const double ee11 = zz - 2.0 * bx[3] + bAb[3];
             const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
-            const double pdet = Psi[0] * Psi[3] - Psi[1] * Psi[2];
-            const double Pi[4] = { Psi[3] / pdet, -Psi[1] / pdet, -Psi[2] / pdet, Psi[0] / pdet };
-            const double l00 = sqrt(Pi[0]), l10 = Pi[1] / l00, l11 = sqrt(Pi[3] - l10 * l10);
+            const double ipdet = q_rcp(Psi[0] * Psi[3] - Psi[1] * Psi[2]);
+            const double Pi[4] = { Psi[3] * ipdet, -Psi[1] * ipdet, -Psi[2] * ipdet, Psi[0] * ipdet };
+            const double l00 = q_sqrt(Pi[0]), l10 = q_div(Pi[1], l00), l11 = q_sqrt(Pi[3] - l10 * l10);
             const double c1 = spd[0], n21 = spd[1], c2 = spd[2];
             const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
             const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
-            const double det = Wm[0] * Wm[3] - Wm[1] * Wm[2];
-            S[0] = Wm[3] / det; S[1] = -Wm[1] / det; S[2] = -Wm[2] / det; S[3] = Wm[0] / det;
+            const double idet = q_rcp(Wm[0] * Wm[3] - Wm[1] * Wm[2]);
+            S[0] = Wm[3] * idet; S[1] = -Wm[1] * idet; S[2] = -Wm[2] * idet; S[3] = Wm[0] * idet;
         } else if (MODEL == LATENT) {
             // drawSubjCovarianceLatent src/Draw.pl.jl:563-579 : InverseGamma(da + N/2, db + sum((zeta - x beta)^2)/2), x = [1 X theta]
             const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1;
@@ -511,7 +515,7 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             for (int u = 0; u < p; ++u) for (int v = 0; v < p; ++v) sr2 += bn[u] * XtX[u + v * PMAX] * bn[v];
             for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
             sr2 += bn[p] * bn[p] * tt;
-            S[3] = (1e-3 + sr2 / 2.0) / spd[0];
+            S[3] = q_div(1e-3 + sr2 / 2.0, spd[0]);
         } else if (MODEL == LATENTQR) {
             // drawSubjCovarianceLatentQr src/Draw.pl.jl:585-606 with the N x N '/' quirk in closed form
             const double* xt = G0; const double tt = G0[p]; const double* xu = G0 + p + 1;
@@ -523,7 +527,7 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             for (int u = 0; u < p; ++u) sr2 += 2.0 * bn[u] * xt[u] * bn[p];
             sr2 += bn[p] * bn[p] * tt;
             const double sw = 2.0 * T.k2 * snu, sw2 = 4.0 * T.k2 * T.k2 * snu2;
-            double quirk = sr2 * sw / sw2;
+            double quirk = q_div(sr2 * sw, sw2);
             if (T.sigp_mode == 1) {
                 // the evidently intended sum_i r_i^2 / (2 k2 nu_i), r = u - x~ beta, from the 1/nu-weighted Gram statistics
                 const int q = p + 1, ntri = q * (q + 1) / 2;
@@ -535,11 +539,11 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
                 quirk = sw_r2 / (2.0 * T.k2);
             }
             const double parB = 1e-3 + quirk + snu;
-            S[3] = parB / spd[0];
+            S[3] = q_div(parB, spd[0]);
         } else {
             // drawSubjCovarianceCross src/Draw.pl.jl:542-557
             const double zz = st1[NSTAT1 * J + 0];
-            S[3] = (1e-3 + zz / 2.0) / spd[0];
+            S[3] = q_div(1e-3 + zz / 2.0, spd[0]);
         }
         if (T.cov2one) d_cov2one(S);
         for (int e = 0; e < 4; ++e) Sigp[e] = S[e];
@@ -710,7 +714,7 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                 const double lam = lp[2 * J + j], sg = lp[3 * J + j];
                 sh_lamc[j] = (real)(lam - lcst[cst_off_m(J) + j]); sh_isig[j] = (real)(1.0 / sg); sh_lsig[j] = (real)log(sg);
             }
-            if (tid == 0) *reinterpret_cast<int*>(sh_struct + 5) = 0;       // sh_ready
+            if (tid == 0) { *reinterpret_cast<int*>(sh_struct + 5) = 0; *reinterpret_cast<unsigned int*>(sh_struct + 7) = 0u; }       // sh_ready, row-group counter
             for (int e = tid; e < nWaves * NG; e += nthr) sh_gacc[e] = 0.0;
         }
         __syncthreads();
@@ -751,7 +755,7 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                 if (lane < 4) v = lp[par_off_sigp(J) + lane];
                 else if (lane >= 8) v = lp[par_off_beta(J) + lane - 8];
                 else if (lane == 4) v = lp[par_off_derived(J)];
-                if (lane != 5) sh_struct[lane] = v;                 // slot 5 is sh_ready
+                if (lane < 5 || lane >= 8) sh_struct[lane] = v;     // slots 5-7: sh_ready, the PG phase's cell counter, the row-sum phase's group counter
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(sh_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -765,24 +769,22 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
 
     const long long row0 = (long long)blockIdx.x * A.rows_per_block;
     const long long row1 = (row0 + A.rows_per_block < A.N) ? row0 + A.rows_per_block : A.N;
-    // wave w owns a contiguous slice [ra, rb) of the workgroup's subjects: balanced, except that a FUSED kernel's wave 0 (busy with the
-    // structural chain first) gets A.skew subjects fewer
     const int nrows_blk = (int)(row1 - row0);
-    long long ra, rb;
-    if (FUSED && nWaves > 1) {
-        int r0 = nrows_blk / nWaves - A.skew; if (r0 < 0) r0 = 0;
-        const int rest = nrows_blk - r0, rbase = rest / (nWaves - 1), rrem = rest % (nWaves - 1);
-        if (wave == 0) { ra = row0; rb = row0 + r0; }
-        else { const int w = wave - 1; ra = row0 + r0 + (long long)w * rbase + (w < rrem ? w : rrem); rb = ra + rbase + (w < rrem ? 1 : 0); }
-    } else {
-        const int rbase = nrows_blk / nWaves, rrem = nrows_blk % nWaves;
-        ra = row0 + (long long)wave * rbase + (wave < rrem ? wave : rrem);
-        rb = ra + rbase + (wave < rrem ? 1 : 0);
-    }
+    // (no wave owns subjects: the row sums take groups of subjects from a counter, the subject draws and the PG phase run over the whole
+    // workgroup, the column phase deals batches of four subjects round-robin)
     ERM_DIAG_STOP(A, 1);
 
     // =================================================================================================== phase 1 (i)
     // sums over each subject's items; lane (r, s): subject r of the group, items s, s+W, ...
+    // Groups of R = 64 / W consecutive subjects of the WORKGROUP are handed to the waves from an LDS counter (a wave's own slice of ~24 subjects
+    // filled only 25 of the 32 row slots of its four groups; and a FUSED kernel's wave 0, busy with the structural chain, simply joins late).
+    // Which wave sums a subject does not matter: the sums go to sh_rs by the subject's position in the workgroup.
+    const int ngroups = (nrows_blk + R - 1) / R;
+    auto next_group = [&]() -> int {
+        unsigned int g = 0u;
+        if (lane == 0) g = atomicAdd(reinterpret_cast<unsigned int*>(sh_struct + 7), 1u);
+        return (int)__builtin_amdgcn_readfirstlane(g);
+    };
 #ifndef ERM_PAIRS_F32
 #define ERM_PAIRS_F32 0
 #endif
@@ -792,10 +794,12 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         // the fp32 engine's 8-byte pairs gained nothing and stay on the scalar path)
         using real2 = typename std::conditional<sizeof(real) == 8, double2, float2>::type;
         const int P = J >> 1, IPP = (P + W - 1) / W;
-        for (long long g0 = ra; g0 < rb; g0 += R) {
-            const long long i = g0 + r;
-            const bool rowok = i < rb;
-            const size_t base = (size_t)(rowok ? i : ra) * J;
+        for (;;) {
+            const int g = next_group();
+            if (g >= ngroups) break;
+            const long long i = row0 + (long long)g * R + r;
+            const bool rowok = i < row1;
+            const size_t base = (size_t)(rowok ? i : row0) * J;
             real s0 = 0, s1 = 0, s2 = 0;
             const real thr = (PHASE == 1 && rowok) ? A.theta[i] : real(0);
             for (int k0 = 0; k0 < IPP; k0 += KB) {
@@ -832,10 +836,12 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
             if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - row0); o[0] = s0; o[1] = s1; o[2] = s2; }
         }
     } else if (A.mode == 1) {
-        for (long long g0 = ra; g0 < rb; g0 += R) {
-            const long long i = g0 + r;
-            const bool rowok = i < rb;
-            const size_t base = (size_t)(rowok ? i : ra) * J;
+        for (;;) {
+            const int g = next_group();
+            if (g >= ngroups) break;
+            const long long i = row0 + (long long)g * R + r;
+            const bool rowok = i < row1;
+            const size_t base = (size_t)(rowok ? i : row0) * J;
             real s0 = 0, s1 = 0, s2 = 0;
             // batches of 4 items per lane with every load issued before any use (clamped index + mask: no branches)
             const real thr = (PHASE == 1 && rowok) ? A.theta[i] : real(0);
@@ -1132,10 +1138,13 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
 
     stamp(9);
     // =================================================================================================== phase 2
-    // lane = item j; a wave takes the subjects of its own slice [ra, rb) from the LAST to the first, so that the phase ends on the rows the
+    // lane = item j; batches of four consecutive subjects are dealt to the waves round-robin (batch b on wave b mod nWaves: a fixed assignment, so
+    // the per-wave partial sums -- and the chain -- are reproducible bit for bit; a wave's own contiguous slice of ~24 subjects filled 24 of the 28
+    // slots of its seven batches), each wave from the LAST batch to the first, so that the phase ends on the rows the
     // next sweep's row sums read first (A/B on one box: 109.7 -> 108.9 us per sweep; FETCH_SIZE is unchanged -- the L2s of a multi-XCD part
     // are written back and invalidated between launches -- so the gain is the memory side's); accumulators live in fp64 registers
     bool p2_done = false;
+    const int nbatch = (nrows_blk + 3) >> 2;
     if constexpr (sizeof(real) == 8 && PHASE == 0 && !fam_cq(MODEL)) {
         // fp64 engine, even test lengths: a lane takes the item PAIR (2l, 2l+1), the two half-waves take two subjects at a time, so that omega
         // and logT come in 16-byte loads (the 8-byte loads of one item per lane reach 0.5-0.7 of that rate); lanes l and l + 32 then hold the
@@ -1152,14 +1161,22 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                 double S0[NSTAT], S1[NSTAT];
 #pragma unroll
                 for (int q = 0; q < NSTAT; ++q) { S0[q] = 0.0; S1[q] = 0.0; }
-                double llc = 0.0;
-                for (long long i0 = rb - 1; i0 >= ra; i0 -= 4) {      // a batch: 2 slots x 2 half-waves = 4 subjects, 4 cells per lane
+                // The phase is VALU-issue-bound (tools/stage_budget.py: 7.5 M wave-instructions, 14 of its 16 us), so the per-cell work is pared down:
+                // statistics go straight into the fp64 accumulators by fma (theta^2 and theta/2 once per subject); the cell log-likelihood
+                //   y eta - log(1 + e^eta) - (log 2 pi + log sig2t_j + er^2 / sig2t_j) / 2
+                // is kept as three per-lane partial sums -- -max(s, 0) with s = eta or -eta by y, the PRODUCT of the factors 1 + e^{-|eta|} (each in
+                // (1, 2]: one logarithm per lane at the end, or every 512 factors), and sum er^2 / sig2t_j -- and the per-item constants enter
+                // once, times the number of cells.
+                double lmax = 0.0, bprod = 1.0, rtq = 0.0;
+                int ncells = 0, nfac = 0;
+                for (int bt = nbatch - 1 - ((nbatch - 1 - wave) % nWaves + nWaves) % nWaves; bt >= 0; bt -= nWaves) {      // a batch: 2 slots x 2 half-waves = 4 subjects, 4 cells per lane
                     double thv[2], zev[2]; double2 wv[2], cv[2]; unsigned int yv[2]; bool okv[2];
+                    const long long i0 = row0 + 4LL * bt + 3;          // the batch's last subject; rows beyond the workgroup's are masked
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const long long i = i0 - (2 * u + half);
-                        okv[u] = jv && i >= ra;
-                        const long long ic = i >= ra ? i : ra;
+                        okv[u] = jv && i < row1;
+                        const long long ic = i < row1 ? i : row0;
                         const size_t e = (size_t)ic * J + jc;
                         thv[u] = A.theta[ic];
                         zev[u] = (MODEL != MLIRT) ? A.zeta[ic] : 0.0;
@@ -1167,35 +1184,35 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                         yv[u] = *reinterpret_cast<const unsigned short*>(gY + e);
                         if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const double2*>(gC + e); else { cv[u].x = 0.0; cv[u].y = 0.0; }
                     }
-                    double bs0[NSTAT], bs1[NSTAT], bl = 0.0, bprod = 1.0;
-#pragma unroll
-                    for (int q = 0; q < NSTAT; ++q) { bs0[q] = 0.0; bs1[q] = 0.0; }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         if (!okv[u]) continue;
-                        const double th = thv[u], ze = zev[u];
-                        auto cell = [&](double w, bool y, double c, double a, double b, double lamc, double isig, double lsig, double* bs) {
-                            const double wt = w * th;
-                            bs[0] += w; bs[1] += wt; bs[2] += wt * th; bs[3] += y ? 0.5 * th : -0.5 * th;
-                            if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) bs[4] += c * ze;
+                        const double th = thv[u], ze = zev[u], th2 = th * th, hth = 0.5 * th;
+                        auto cell = [&](double w, bool y, double c, double a, double b, double lamc, double isig, double* S) {
+                            S[0] += w; S[1] = fma(w, th, S[1]); S[2] = fma(w, th2, S[2]); S[3] += y ? hth : -hth;
+                            if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) S[4] = fma(c, ze, S[4]);
                             if (A.mode == 1) {
                                 const double eta = a * (th - b);
-                                double t = (y ? eta : 0.0) - (eta > 0.0 ? eta : 0.0);
+                                const double sgn = y ? -eta : eta;                  // y eta - max(eta, 0) = -max(sgn, 0)
+                                lmax += sgn > 0.0 ? sgn : 0.0;
                                 bprod *= 1.0 + fm::exp_neg(fabs(eta));
                                 if (fam_rt(MODEL) || fam_lq(MODEL)) {
                                     const double er = c + ze - lamc;
-                                    t += -0.5 * (LOG_2PI + lsig + er * er * isig);
+                                    rtq = fma(er * er, isig, rtq);
                                 }
-                                bl += t;
                             }
                         };
-                        cell(wv[u].x, (yv[u] & 0xFFu) != 0u, cv[u].x, a0, b0, lamc0, isig0, lsig0, bs0);
-                        cell(wv[u].y, (yv[u] >> 8) != 0u, cv[u].y, a1, b1, lamc1, isig1, lsig1, bs1);
+                        cell(wv[u].x, (yv[u] & 0xFFu) != 0u, cv[u].x, a0, b0, lamc0, isig0, S0);
+                        cell(wv[u].y, (yv[u] >> 8) != 0u, cv[u].y, a1, b1, lamc1, isig1, S1);
+                        ++ncells;
                     }
-#pragma unroll
-                    for (int q = 0; q < NSTAT; ++q) { S0[q] += bs0[q]; S1[q] += bs1[q]; }
-                    if (A.mode == 1) bl -= fm::log(bprod, logtab);
-                    llc += bl;
+                    nfac += 4;
+                    if (A.mode == 1 && nfac >= 512) { lmax += fm::log(bprod, logtab); bprod = 1.0; nfac = 0; }     // (wave-uniform) keeps the product below 2^1023
+                }
+                double llc = 0.0;
+                if (A.mode == 1) {
+                    llc = -(lmax + fm::log(bprod, logtab));
+                    if (fam_rt(MODEL) || fam_lq(MODEL)) llc -= 0.5 * (rtq + (double)ncells * (2.0 * LOG_2PI + lsig0 + lsig1));
                 }
 #pragma unroll
                 for (int q = 0; q < NSTAT; ++q) { S0[q] += __shfl_xor(S0[q], 32, 64); S1[q] += __shfl_xor(S1[q], 32, 64); }
@@ -1218,13 +1235,14 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         for (int q = 0; q < NSTAT; ++q) S[q] = 0.0;
         double llc = 0.0;
         const int jc = jv ? j : 0;
-        for (long long i0 = rb - 1; i0 >= ra; i0 -= 4) {
+        for (int bt = nbatch - 1 - ((nbatch - 1 - wave) % nWaves + nWaves) % nWaves; bt >= 0; bt -= nWaves) {
             real thv[4], zev[4], wv[4], cv[4], nv[4]; bool yv[4], okv[4]; long long iv[4];
+            const long long i0 = row0 + 4LL * bt + 3;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                 // every load of the batch is issued before any use
                 const long long i = i0 - u;
-                okv[u] = jv && i >= ra;
-                iv[u] = i >= ra ? i : ra;
+                okv[u] = jv && i < row1;
+                iv[u] = i < row1 ? i : row0;
                 const size_t e = (size_t)iv[u] * J + jc;
                 thv[u] = A.theta[iv[u]];
                 zev[u] = (MODEL != MLIRT) ? A.zeta[iv[u]] : real(0);

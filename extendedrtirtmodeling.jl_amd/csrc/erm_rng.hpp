@@ -151,6 +151,9 @@ __device__ __forceinline__ float  q_sqrt(float x)  { return r_sqrt(x); }
 __device__ __forceinline__ double q_sqrt(double x) { return fm::sqrt(x); }
 __device__ __forceinline__ float  q_log(float x)  { return r_log(x); }
 __device__ __forceinline__ double q_log(double x) { return fm::log(x); }
+__device__ __forceinline__ float  q_cos2pi(float x)  { return r_cos2pi(x); }
+__device__ __forceinline__ double q_cos2pi(double x) { return fm::cos2pi(x); }
+__device__ __forceinline__ double q_exp_neg(double a) { return fm::exp_neg(a); }       // e^{-a}, a >= 0
 
 template <typename real> struct Const;
 template <> struct Const<float> {
@@ -212,12 +215,12 @@ template <typename real> __device__ __forceinline__ real uniform(Stream& s);
 template <> __device__ __forceinline__ double uniform<double>(Stream& s) { return ((double)s.next() + 0.5) * (1.0 / 4294967296.0); }
 template <> __device__ __forceinline__ float uniform<float>(Stream& s) { return ((float)(s.next() >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
-template <typename real> __device__ __forceinline__ real expo(Stream& s) { return -r_log(uniform<real>(s)); }
+template <typename real> __device__ __forceinline__ real expo(Stream& s) { return -q_log(uniform<real>(s)); }       // uniforms are normal numbers in (0, 1)
 
 template <typename real> __device__ __forceinline__ real normal(Stream& s)
 {
     const real u1 = uniform<real>(s), u2 = uniform<real>(s);
-    return r_sqrt(real(-2) * r_log(u1)) * r_cos2pi(u2);
+    return q_sqrt(real(-2) * q_log(u1)) * q_cos2pi(u2);
 }
 
 // fp64 cell path: the same variate from the range-specialised functions (uniforms are normal, finite numbers in (0, 1))
@@ -542,17 +545,20 @@ template <typename real> __device__ __forceinline__ real pg1(Stream& s, real c, 
 // ---- item-level samplers (fp64 only) --------------------------------------------------------
 __device__ __forceinline__ double truncnorm0(Stream& s, double m, double sd)
 {
-    const double alpha = -m / sd;
+    // (the item-level draws are dependent fp64 chains on a handful of lanes -- the head of every sweep waits for them: range-specialised
+    // division / root / exponential instead of the IEEE and OCML sequences, cf. namespace fm)
+    const double alpha = -q_div(m, sd);
     double z;
     int tries = 0;
     if (alpha <= 0.0) {
         do { z = normal<double>(s); } while (z < alpha && ++tries < MAX_TRIES);
     } else {
-        const double lam = 0.5 * (alpha + sqrt(alpha * alpha + 4.0));
+        const double lam = 0.5 * (alpha + q_sqrt(alpha * alpha + 4.0));
+        const double ilam = q_rcp(lam);
         for (;;) {
-            z = alpha + expo<double>(s) / lam;
+            z = alpha + expo<double>(s) * ilam;
             const double u = uniform<double>(s);
-            if (u <= exp(-0.5 * (z - lam) * (z - lam)) || ++tries >= MAX_TRIES) break;
+            if (u <= q_exp_neg(0.5 * (z - lam) * (z - lam)) || ++tries >= MAX_TRIES) break;
         }
     }
     return m + sd * z;
@@ -560,7 +566,7 @@ __device__ __forceinline__ double truncnorm0(Stream& s, double m, double sd)
 
 __device__ __forceinline__ double gamma_mt(Stream& s, double shape)
 {
-    const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    const double d = shape - 1.0 / 3.0, c = q_rcp(q_sqrt(9.0 * d));
     for (int tries = 0;; ++tries) {
         double x, v;
         do { x = normal<double>(s); v = 1.0 + c * x; } while (v <= 0.0 && ++tries < MAX_TRIES);
@@ -568,11 +574,12 @@ __device__ __forceinline__ double gamma_mt(Stream& s, double shape)
         const double u = uniform<double>(s);
         const double x2 = x * x;
         if (u < 1.0 - 0.0331 * x2 * x2) return d * v;         // Marsaglia-Tsang squeeze: implies the log test below, so it changes no decision
-        if (log(u) < 0.5 * x2 + d - d * v + d * log(v)) return d * v;
+        if (!(v >= 1e-300)) { if (tries >= MAX_TRIES) return __builtin_nan(""); continue; }      // (1 + c x)^3 underflowed: the log test below fails for every u
+        if (q_log(u) < 0.5 * x2 + d - d * v + d * q_log(v)) return d * v;
         if (tries >= MAX_TRIES) return __builtin_nan("");
     }
 }
-__device__ __forceinline__ double invgamma(Stream& s, double shape, double scale) { return scale / gamma_mt(s, shape); }
+__device__ __forceinline__ double invgamma(Stream& s, double shape, double scale) { return q_div(scale, gamma_mt(s, shape)); }
 __device__ __forceinline__ double chisq(Stream& s, double k) { return 2.0 * gamma_mt(s, 0.5 * k); }
 
 // GIG(p, a, b), density proportional to x^(p-1) exp(-(a x + b/x)/2): the distribution type of src/GenInvGaussian.jl (dead code in the

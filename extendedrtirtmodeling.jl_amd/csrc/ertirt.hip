@@ -371,7 +371,7 @@ template <typename real> struct Engine : EngineBase {
     // skew >= 0 and at most a wave's share of the workgroup's rows: anything else is clamped.  ERM_SKEW is a tuning knob of the
     // diagnostic build only.
     int skew_rows() const {
-        int k = 2;
+        int k = 0;       // (round 2: 2 -- wave 0 used to own its row sums; they are dealt dynamically now and the column phase starts behind a barrier)
 #ifdef ERM_DIAG_BUILD
         if (const char* e = getenv("ERM_SKEW")) k = atoi(e);
 #endif
