@@ -369,6 +369,11 @@ def roofline(model, N, J, n_loc, precision, tm):
            "launch_us_source": "HIP events on the engine's stream around sweep-kernel launches of the timed region (live)"}
     if off is not None and off.get("valu") is not None:
         out["valu"] = dict(off["valu"], source="offline rocprofv3 SQ counters (profiles/), not measured in this run")
+        # what actually limits the kernel: VALU issue in its Polya-Gamma and column phases (profiles/round3_budget_*.md itemises it stage by stage)
+        out["bound_actual"] = "valu"
+        out["valu_issue_frac"] = off["valu"].get("valu_busy_frac")
+        out["bound_note"] = ("nominally HBM-bound (SURVEY.md 8(d)); measured: the VALUs are busy for valu_issue_frac of the kernel's cycles (offline SQ counters), the rest is the "
+                             "latency of its serial head / tail; HBM-side traffic is far from the 8 TB/s peak")
     return out
 
 
@@ -422,7 +427,7 @@ def main_farm(args, world_env):
     if driver:      # Post.mean over iterations and chains: the ONE collective of the path (the library's RCCL all-reduce)
         farm.get_mean()
         g = farm.timing()
-        gather = {"gather_ms": g["gather_ms"], "allreduce_ms": g["allreduce_ms"], "rccl_ranks": g["rccl_ranks"], "n_devices": g["n_devices"], "used_rccl": farm.used_rccl,
+        gather = {"gather_ms": g["gather_ms"], "allreduce_ms": g["allreduce_ms"], "comm_init_ms": g["comm_init_ms"], "rccl_ranks": g["rccl_ranks"], "n_devices": g["n_devices"], "used_rccl": farm.used_rccl,
                   "post_count": farm.post_count}
         del farm
     fp32 = None

@@ -47,7 +47,7 @@ FLAG_NO_FUSE, FLAG_NO_GRAPH, FLAG_FARM_FORCE_RCCL = 1, 2, 4
 
 
 class erm_farm_timing(C.Structure):
-    _fields_ = [("run_wall_ms", C.c_double), ("gather_ms", C.c_double), ("allreduce_ms", C.c_double), ("rccl_ranks", C.c_int32), ("n_devices", C.c_int32)]
+    _fields_ = [("run_wall_ms", C.c_double), ("gather_ms", C.c_double), ("allreduce_ms", C.c_double), ("comm_init_ms", C.c_double), ("rccl_ranks", C.c_int32), ("n_devices", C.c_int32)]
 
 
 _DP = C.POINTER(C.c_double)

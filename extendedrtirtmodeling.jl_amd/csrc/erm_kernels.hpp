@@ -1070,7 +1070,9 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                     if (unsure) { acc_ = a2; w = (real)o2; }
                 }
                 if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
-                    om[c] = w;
+                    // write-through (sc1) store: omega_{t+1} is next read by the column phase (behind a barrier) and by the next launch, and nothing of it
+                    // stays dirty in L2 for the end-of-kernel write-back (A/B on one box: 75.9-76.2 -> 75.4-75.7 us per sweep)
+                    __hip_atomic_store(om + c, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     c = (int)atomicAdd(qhead, 1u);
                     att = 0;
                     active = c < ncell;

@@ -1474,6 +1474,7 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
     const bool force = (f->cfg.flags & ERM_FLAG_FARM_FORCE_RCCL) != 0;
     f->used_rccl = false;
     f->tm.allreduce_ms = 0.0;
+    double init_ms = 0.0;                     // communicator creation inside THIS call (first reduction only): reported apart from gather_ms
     if (nd > 1 || force) {
         if (int rc = g_rccl.load()) return rc;
         if (f->rstream.empty()) {
@@ -1481,9 +1482,12 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
             for (int d = 0; d < nd; ++d) { HIPCHK(hipSetDevice(f->udev[d])); HIPCHK(hipStreamCreateWithFlags(&f->rstream[d], hipStreamNonBlocking)); }
         }
         if (f->comms.empty()) {
+            const auto c0 = std::chrono::steady_clock::now();
             f->comms.assign(nd, nullptr);
             const ncclResult_t r = g_rccl.CommInitAll(f->comms.data(), nd, f->udev.data());
             if (r != ncclSuccess) { f->comms.clear(); return fail(ERM_ERR_STATE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
+            f->tm.comm_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+            init_ms = f->tm.comm_init_ms;
         }
         const auto a0 = std::chrono::steady_clock::now();
         // a group that has been started is always ended, whatever happens inside it
@@ -1508,7 +1512,7 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
     const double inv = 1.0 / (double)total;
     for (auto& v : m) v *= inv;
     const int rc = f->eng[0]->e->summary_unpack(m.data(), out);
-    f->tm.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    f->tm.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - init_ms;
     return rc;
 }
 

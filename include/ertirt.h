@@ -188,10 +188,11 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out);
 int64_t erm_farm_post_count(erm_farm_handle f);
 int erm_farm_used_rccl(erm_farm_handle f);                  /* 1 if the last erm_farm_get_mean reduced over RCCL */
 /* What a multi-GPU benchmark of the farm reports: wall-clock of the last erm_farm_run (all chains, host side), the device time of each chain's
- * last erm_run (run_ms[n_chains], may be NULL), the wall-clock of the last erm_farm_get_mean and of its all-reduce alone, and the number of ranks
+ * last erm_run (run_ms[n_chains], may be NULL), the wall-clock of the last erm_farm_get_mean (without the one-off communicator creation) and of its all-reduce alone, and the number of ranks
  * of the library's own RCCL communicator (ncclCommCount; 0 if no communicator exists). */
 typedef struct {
     double run_wall_ms, gather_ms, allreduce_ms;
+    double comm_init_ms;    /* ncclCommInitAll, paid by the first erm_farm_get_mean over more than one device (not part of gather_ms) */
     int32_t rccl_ranks, n_devices;
 } erm_farm_timing;
 int erm_farm_get_timing(erm_farm_handle f, erm_farm_timing* out, double* run_ms);

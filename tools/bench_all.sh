@@ -10,3 +10,5 @@ run driver20 --steps 20 --warmup 5 --cpu-sweeps 0
 for m in mlirt latentqr crossqr null cross latent; do run $m --model $m --cpu-sweeps 0; done
 run 500kx100 --nsubj 500000 --nitem 100 --steps 200 --warmup 20 --cpu-sweeps 0
 run summary --trace summary --cpu-sweeps 0
+# the N > 1 path rehearsed on this one-GPU box: two chains of the C-ABI farm on device 0, the reduction through the library's RCCL communicator (one rank)
+ERM_BENCH_REHEARSE=1 run farm2_rehearsal --gpus 2 --steps 200 --warmup 20 --cpu-sweeps 0
