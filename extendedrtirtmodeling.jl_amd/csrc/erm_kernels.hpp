@@ -770,6 +770,13 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
     const long long row0 = (long long)blockIdx.x * A.rows_per_block;
     const long long row1 = (row0 + A.rows_per_block < A.N) ? row0 + A.rows_per_block : A.N;
     const int nrows_blk = (int)(row1 - row0);
+    // the workgroup's first cell / subject: offsets inside the workgroup fit 32 bits (< 2^22 cells), so no 64-bit index arithmetic per row
+    [[maybe_unused]] const real* blk_omega = A.omega + (size_t)row0 * J;
+    [[maybe_unused]] const uint8_t* blk_Y = gY + (size_t)row0 * J;
+    [[maybe_unused]] const real* blk_C = (MODEL != MLIRT) ? gC + (size_t)row0 * J : nullptr;
+    [[maybe_unused]] const real* blk_theta = A.theta + row0;
+    [[maybe_unused]] const real* blk_zeta = A.zeta + row0;
+    [[maybe_unused]] const real* blk_nu = (has_nu(MODEL) && fam_cq(MODEL)) ? A.nu + (size_t)row0 * J : nullptr;
     // (no wave owns subjects: the row sums take groups of subjects from a counter, the subject draws and the PG phase run over the whole
     // workgroup, the column phase deals batches of four subjects round-robin)
     ERM_DIAG_STOP(A, 1);
@@ -797,9 +804,10 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         for (;;) {
             const int g = next_group();
             if (g >= ngroups) break;
-            const long long i = row0 + (long long)g * R + r;
-            const bool rowok = i < row1;
-            const size_t base = (size_t)(rowok ? i : row0) * J;
+            const int qrow = g * R + r;                        // the subject's position in the workgroup
+            const bool rowok = qrow < nrows_blk;
+            const long long i = row0 + qrow;
+            const unsigned int base = (unsigned int)(rowok ? qrow : 0) * (unsigned int)J;      // 32-bit offsets from the workgroup's first cell (< 2^22)
             real s0 = 0, s1 = 0, s2 = 0;
             const real thr = (PHASE == 1 && rowok) ? A.theta[i] : real(0);
             for (int k0 = 0; k0 < IPP; k0 += KB) {
@@ -809,10 +817,10 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                     const int q = s + W * (k0 + u);
                     ok4[u] = rowok && (k0 + u) < IPP && q < P;
                     jv4[u] = ok4[u] ? 2 * q : 0;
-                    const size_t e = base + jv4[u];
-                    if constexpr (PHASE == 0) { wv[u] = *reinterpret_cast<const real2*>(A.omega + e); yv[u] = *reinterpret_cast<const unsigned short*>(gY + e); }
-                    else { yv[u] = 0u; if constexpr (has_nu(MODEL)) wv[u] = *reinterpret_cast<const real2*>(A.nu + e); else { wv[u].x = real(1); wv[u].y = real(1); } }
-                    if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const real2*>(gC + e); else { cv[u].x = real(0); cv[u].y = real(0); }
+                    const unsigned int e = base + (unsigned int)jv4[u];
+                    if constexpr (PHASE == 0) { wv[u] = *reinterpret_cast<const real2*>(blk_omega + e); yv[u] = *reinterpret_cast<const unsigned short*>(blk_Y + e); }
+                    else { yv[u] = 0u; if constexpr (has_nu(MODEL)) wv[u] = *reinterpret_cast<const real2*>(blk_nu + e); else { wv[u].x = real(1); wv[u].y = real(1); } }
+                    if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const real2*>(blk_C + e); else { cv[u].x = real(0); cv[u].y = real(0); }
                 }
 #pragma unroll
                 for (int u = 0; u < KB; ++u) {
@@ -833,15 +841,16 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
             }
             s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W);
             if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
-            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - row0); o[0] = s0; o[1] = s1; o[2] = s2; }
+            if (rowok && s == 0) { real* o = sh_rs + 3 * qrow; o[0] = s0; o[1] = s1; o[2] = s2; }
         }
     } else if (A.mode == 1) {
         for (;;) {
             const int g = next_group();
             if (g >= ngroups) break;
-            const long long i = row0 + (long long)g * R + r;
-            const bool rowok = i < row1;
-            const size_t base = (size_t)(rowok ? i : row0) * J;
+            const int qrow = g * R + r;
+            const bool rowok = qrow < nrows_blk;
+            const long long i = row0 + qrow;
+            const unsigned int base = (unsigned int)(rowok ? qrow : 0) * (unsigned int)J;
             real s0 = 0, s1 = 0, s2 = 0;
             // batches of 4 items per lane with every load issued before any use (clamped index + mask: no branches)
             const real thr = (PHASE == 1 && rowok) ? A.theta[i] : real(0);
@@ -852,10 +861,10 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                     const int j = s + W * (k0 + u);
                     ok4[u] = rowok && (k0 + u) < IPL && j < J;
                     jv4[u] = ok4[u] ? j : 0;
-                    const size_t e = base + jv4[u];
-                    wv[u] = (PHASE == 0) ? A.omega[e] : (has_nu(MODEL) ? A.nu[e] : real(1));
-                    yv[u] = (PHASE == 0) ? (real)gY[e] : real(0);
-                    cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
+                    const unsigned int e = base + (unsigned int)jv4[u];
+                    wv[u] = (PHASE == 0) ? blk_omega[e] : (has_nu(MODEL) ? blk_nu[e] : real(1));
+                    yv[u] = (PHASE == 0) ? (real)blk_Y[e] : real(0);
+                    cv[u] = (MODEL != MLIRT) ? blk_C[e] : real(0);
                 }
 #pragma unroll
                 for (int u = 0; u < KB; ++u) {
@@ -876,7 +885,7 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
             }
             s0 = bfly_sum(s0, 1, W); s2 = bfly_sum(s2, 1, W);
             if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
-            if (rowok && s == 0) { real* o = sh_rs + 3 * (int)(i - row0); o[0] = s0; o[1] = s1; o[2] = s2; }
+            if (rowok && s == 0) { real* o = sh_rs + 3 * qrow; o[0] = s0; o[1] = s1; o[2] = s2; }
         }
     }
     // every wave's row sums (and, FUSED, wave 0's structural results in sh_struct: it stored them before its own row sums) are visible to
@@ -1173,18 +1182,18 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                 int ncells = 0, nfac = 0;
                 for (int bt = nbatch - 1 - ((nbatch - 1 - wave) % nWaves + nWaves) % nWaves; bt >= 0; bt -= nWaves) {      // a batch: 2 slots x 2 half-waves = 4 subjects, 4 cells per lane
                     double thv[2], zev[2]; double2 wv[2], cv[2]; unsigned int yv[2]; bool okv[2];
-                    const long long i0 = row0 + 4LL * bt + 3;          // the batch's last subject; rows beyond the workgroup's are masked
+                    const int q0 = 4 * bt + 3;                         // the batch's last subject (position in the workgroup); rows beyond the workgroup's are masked
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const long long i = i0 - (2 * u + half);
-                        okv[u] = jv && i < row1;
-                        const long long ic = i < row1 ? i : row0;
-                        const size_t e = (size_t)ic * J + jc;
-                        thv[u] = A.theta[ic];
-                        zev[u] = (MODEL != MLIRT) ? A.zeta[ic] : 0.0;
-                        wv[u] = *reinterpret_cast<const double2*>(A.omega + e);
-                        yv[u] = *reinterpret_cast<const unsigned short*>(gY + e);
-                        if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const double2*>(gC + e); else { cv[u].x = 0.0; cv[u].y = 0.0; }
+                        const int q = q0 - (2 * u + half);
+                        okv[u] = jv && q < nrows_blk;
+                        const int qc = q < nrows_blk ? q : 0;
+                        const unsigned int e = (unsigned int)qc * (unsigned int)J + (unsigned int)jc;      // < 2^22: 32-bit offsets from the workgroup's first cell
+                        thv[u] = blk_theta[qc];
+                        zev[u] = (MODEL != MLIRT) ? blk_zeta[qc] : 0.0;
+                        wv[u] = *reinterpret_cast<const double2*>(blk_omega + e);
+                        yv[u] = *reinterpret_cast<const unsigned short*>(blk_Y + e);
+                        if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const double2*>(blk_C + e); else { cv[u].x = 0.0; cv[u].y = 0.0; }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -1239,19 +1248,20 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         const int jc = jv ? j : 0;
         for (int bt = nbatch - 1 - ((nbatch - 1 - wave) % nWaves + nWaves) % nWaves; bt >= 0; bt -= nWaves) {
             real thv[4], zev[4], wv[4], cv[4], nv[4]; bool yv[4], okv[4]; long long iv[4];
-            const long long i0 = row0 + 4LL * bt + 3;
+            const int q0 = 4 * bt + 3;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                 // every load of the batch is issued before any use
-                const long long i = i0 - u;
-                okv[u] = jv && i < row1;
-                iv[u] = i < row1 ? i : row0;
-                const size_t e = (size_t)iv[u] * J + jc;
-                thv[u] = A.theta[iv[u]];
-                zev[u] = (MODEL != MLIRT) ? A.zeta[iv[u]] : real(0);
-                wv[u] = (PHASE == 0) ? A.omega[e] : real(0);
-                yv[u] = (PHASE == 0) ? (gY[e] != 0) : false;
-                cv[u] = (MODEL != MLIRT) ? gC[e] : real(0);
-                nv[u] = (MODEL == CROSSQR) ? A.nu[e] : real(1);
+                const int q = q0 - u;
+                okv[u] = jv && q < nrows_blk;
+                const int qc = q < nrows_blk ? q : 0;
+                iv[u] = row0 + qc;
+                const unsigned int e = (unsigned int)qc * (unsigned int)J + (unsigned int)jc;      // 32-bit offset from the workgroup's first cell
+                thv[u] = blk_theta[qc];
+                zev[u] = (MODEL != MLIRT) ? blk_zeta[qc] : real(0);
+                wv[u] = (PHASE == 0) ? blk_omega[e] : real(0);
+                yv[u] = (PHASE == 0) ? (blk_Y[e] != 0) : false;
+                cv[u] = (MODEL != MLIRT) ? blk_C[e] : real(0);
+                nv[u] = (MODEL == CROSSQR) ? blk_nu[e] : real(1);
             }
             // the 4 cells of a batch are summed in `real` and enter the fp64 accumulators once per batch (fp64 VALU work is what bounds
             // this phase; a 4-term fp32 sum costs ~1 ulp of its terms' own rounding)
