@@ -287,7 +287,7 @@ template <typename real> struct Engine : EngineBase {
             if (cfg.model == ERM_MODEL_LATENTQR) rc |= dTrNu.alloc((size_t)rows_cap * N * sizeof(real));
             if (cfg.model == ERM_MODEL_CROSSQR) {
                 // Post.qr of GibbsRtIrtCrossQr carries vec(nu) (N*J values) per sweep (src/GibbsRtIrtCross.pl.jl:65,296): kept on the device
-                // when it fits the budget (ERM_NU_TRACE_MAX_GB, default 16), otherwise only nu's running mean is available
+                // when it fits the budget (erm_config.nu_trace_max_gb, default 16 GiB), otherwise only nu's running mean is available
                 const double cap_gb = cfg.nu_trace_max_gb > 0.0 ? cfg.nu_trace_max_gb : 16.0;
                 const double need_gb = (double)rows_cap * (double)NJ * sizeof(real) / 1073741824.0;
                 if (need_gb <= cap_gb) rc |= dTrNu.alloc((size_t)rows_cap * NJ * sizeof(real));
@@ -1051,7 +1051,7 @@ template <typename real> struct Engine : EngineBase {
         }
         if (cfg.trace_mode != ERM_TRACE_FULL) return fail(ERM_ERR_NOTRACE, "subject-level traces need trace_mode = ERM_TRACE_FULL");
         if (which == ERM_TRACE_QR && cfg.model == ERM_MODEL_CROSSQR && !dTrNu.p)
-            return fail(ERM_ERR_NOTRACE, "the per-sweep nu trace (N*J values per sweep) exceeds ERM_NU_TRACE_MAX_GB; use erm_get_item_trace (rho, Sigp) + erm_get_mean (nu)");
+            return fail(ERM_ERR_NOTRACE, "the per-sweep nu trace (N*J values per sweep) exceeds erm_config.nu_trace_max_gb; use erm_get_item_trace (rho, Sigp) + erm_get_mean (nu)");
         std::vector<double> it;
         if (int rc = fetch_item_trace(it)) return rc;
         const int64_t wi = item_trace_width();
@@ -1151,7 +1151,7 @@ template <typename real> struct Engine : EngineBase {
             if (cfg.model == ERM_MODEL_LATENTQR) { if (int rc = launch_real(dTrNu, N, q)) return rc; }
             if (cfg.model == ERM_MODEL_CROSSQR) {
                 // vec(nu) in Post.qr is column-major N x J; the device trace is row-major: diagnose in device order, permute on the host
-                if (!dTrNu.p) return fail(ERM_ERR_NOTRACE, "the per-sweep nu trace was not recorded (ERM_NU_TRACE_MAX_GB)");
+                if (!dTrNu.p) return fail(ERM_ERR_NOTRACE, "the per-sweep nu trace was not recorded (erm_config.nu_trace_max_gb)");
                 DevBuf e2, r2;
                 if (int rc = e2.alloc((size_t)N * J * sizeof(double))) return rc;
                 if (int rc = r2.alloc((size_t)N * J * sizeof(double))) return rc;

@@ -227,7 +227,7 @@ function sample!(M::GibbsAMD; intercept = false, itemtype::Union{String} = "2pl"
     Post.ra = trace(TRACE_RA)
     Post.logLike = trace(TRACE_LOGLIKE)
     modelid(M) != MODEL_MLIRT && (Post.rt = trace(TRACE_RT))
-    Post.qr = trace(TRACE_QR)        # CrossQr: errors if vec(nu) per sweep exceeds ERM_NU_TRACE_MAX_GB (then use erm_get_item_trace)
+    Post.qr = trace(TRACE_QR)        # CrossQr: errors if vec(nu) per sweep exceeds erm_config.nu_trace_max_gb (then use erm_get_item_trace)
 
     N, J, F = C.nSubj, C.nItem, C.nFeat
     nb = modelid(M) == MODEL_MLIRT ? F + 1 : modelid(M) in (MODEL_RTIRT, MODEL_NULL) ? 2 * (F + 1) : modelid(M) in (MODEL_LATENTQR, MODEL_LATENT) ? F + 2 : 0

@@ -101,7 +101,8 @@ def test_stage_timing_knobs_do_not_exist_in_the_shipped_library(monkeypatch):
     that leave garbage results.  The shipped library compiles none of that code, so a variable left exported cannot touch a fit."""
     Y, logT, X, init, _ = pu.make_problem("rtirt", 700, 9)
     ref = pu.run_device("rtirt", Y, logT, X, init, 6, precision="f64")
-    for name, val in (("ERM_PASS_STOP", "3"), ("ERM_PASS_STOP", "9"), ("ERM_TINY_STOP", "1"), ("ERM_SKEW", "-7"), ("ERM_SKEW", "100000")):
+    for name, val in (("ERM_PASS_STOP", "3"), ("ERM_PASS_STOP", "9"), ("ERM_TINY_STOP", "1"), ("ERM_SKEW", "-7"), ("ERM_SKEW", "100000"), ("ERM_STOP_SWEEP", "2"),
+                      ("ERM_NO_FUSE", "1"), ("ERM_NO_GRAPH", "1"), ("ERM_FARM_FORCE_RCCL", "1"), ("ERM_NU_TRACE_MAX_GB", "0.000001"), ("ERM_TIMELINE", "1")):
         monkeypatch.setenv(name, val)
         for prec in ("f64", "f32"):
             got = pu.run_device("rtirt", Y, logT, X, init, 6, precision=prec)
@@ -110,6 +111,34 @@ def test_stage_timing_knobs_do_not_exist_in_the_shipped_library(monkeypatch):
             else:
                 assert np.all(np.isfinite(got["ra"])) and np.max(np.abs(got["item"] - ref["item"])) < 5e-2, (name, val)
         monkeypatch.delenv(name)
+
+
+@pytest.mark.parametrize("model", ["rtirt", "mlirt", "latentqr"])
+def test_schedule_flags_change_the_schedule_not_the_chain(model):
+    """erm_config.flags (round 3: schedule switches are config fields, not environment variables): ERM_FLAG_NO_FUSE = stand-alone tiny kernel + row pass
+    instead of the fused sweep kernel, ERM_FLAG_NO_GRAPH = every sweep enqueued instead of the replayed 32-sweep hipGraph.  Same chain: item-level draws
+    agree to rounding of the statistics' summation (the fused head and the tiny kernel reduce the same rows in the same order: bit-identical)."""
+    Y, logT, X, init, _ = pu.make_problem(model, 900, 9)
+    T = 40                                    # long enough for the 32-sweep graph
+    ref = pu.run_device(model, Y, logT, X, init, T, precision="f64")
+    for flags in (L.FLAG_NO_GRAPH, L.FLAG_NO_FUSE, L.FLAG_NO_FUSE | L.FLAG_NO_GRAPH):
+        got = pu.run_device(model, Y, logT, X, init, T, precision="f64", flags=flags)
+        assert np.array_equal(got["ra"], ref["ra"]) and np.array_equal(got["item"], ref["item"]) and np.array_equal(got["ll"], ref["ll"]), flags
+
+
+def test_nu_trace_budget_is_a_config_field():
+    """GibbsRtIrtCrossQr's Post.qr carries vec(nu) per sweep; erm_config.nu_trace_max_gb bounds the device memory it may take (default 16 GiB)."""
+    Y, logT, X, init, _ = pu.make_problem("crossqr", 200, 6)
+    full = pu.run_device("crossqr", Y, logT, X, init, 4, precision="f64")
+    assert full["qr"].shape[1] == 6 + 4 + 200 * 6
+    eng = L.Engine(model=pu.MODELS["crossqr"], n_item=6, n_subj=200, n_feat=0, n_iter=4, n_chain=1, n_burnin=2, cov2one=1, q_rt=0.85, seed=1234, precision=1, trace_mode=1,
+                   nu_trace_max_gb=1e-7)
+    eng.set_data(Y, logT, None)
+    eng.set_state(**init)
+    eng.run(4)
+    with pytest.raises(L.ErmError, match="nu trace"):
+        eng.trace(L.TRACE_QR)
+    assert np.array_equal(eng.item_trace(), full["item"])
 
 
 def test_a_failed_run_poisons_the_engine_until_a_state_is_installed():
