@@ -907,6 +907,9 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
     // bivariate-normal log-density constants of Sigma_p (src/GibbsRtIrt.pl.jl:268-269)
     const double sp_det = sh_struct[0] * sh_struct[3] - sh_struct[1] * sh_struct[2];
     const double sp_idet = q_rcp(sp_det);
+    // LatentQr's quantile weights (fp64): cB = sqrt(2 k2 + k1^2), lambda = parB^2 = (2 k2 + k1^2) / (Sigp22 k2), once per wave
+    [[maybe_unused]] const double lq_cB = sqrt((double)(real(2) * k2 + k1 * k1));
+    [[maybe_unused]] const double lq_lam = (double)(real(2) * k2 + k1 * k1) / ((double)sig22 * (double)k2);
     const double sp_c0 = -LOG_2PI - 0.5 * q_log(sp_det);
     const double sp_q00 = sh_struct[3] * sp_idet, sp_q01 = -(sh_struct[1] + sh_struct[2]) * sp_idet, sp_q11 = sh_struct[0] * sp_idet;
     for (int q0 = (int)threadIdx.x & ~63; q0 < nrows_blk; q0 += (int)blockDim.x) {
@@ -1003,11 +1006,12 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         }
         if (MODEL == LATENTQR) {
             // nu_{t+1}: src/Draw.pl.jl:325-343 (depends on zeta_t, theta_t, beta_t, Sigp_t only)
-            const real den = r_sqrt(sig22 * k2);
-            const real parA = r_div(r_abs(ze - xb5), den);
-            const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
             Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i + A.row_base, 0u, sweep + 1u);
-            nu_next = qr_weight<real>(st, parA, parB, logtab);
+            if constexpr (sizeof(real) == 8) nu_next = qr_weight_q(st, fabs(ze - xb5), lq_cB, lq_lam, logtab);
+            else {
+                const real den = r_sqrt(sig22 * k2);
+                nu_next = qr_weight<real>(st, r_div(r_abs(ze - xb5), den), r_div(r_sqrt(real(2) * k2 + k1 * k1), den), logtab);
+            }
             if (rok) A.nu[i] = nu_next;
         }
 
@@ -1241,6 +1245,9 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         const real a = jv ? sh_a[j] : real(0), b = jv ? sh_b[j] : real(0);
         const real lamc = jv ? sh_lamc[j] : real(0), isig = jv ? sh_isig[j] : real(1), lsig = jv ? sh_lsig[j] : real(0);
         const real rho = jv ? sh_rho[j] : real(0);
+        // quantile weights (CrossQr pass B, fp64): the scale-free constants of the inverse-Gaussian draw, once per item
+        [[maybe_unused]] const double qr_cB = sqrt((double)(real(2) * k2 + k1 * k1));
+        [[maybe_unused]] const double qr_lam = (double)(real(2) * k2 + k1 * k1) * (double)isig / (double)k2;       // parB^2 = (2 k2 + k1^2) / (sig2t k2)
         double S[NSTAT];
 #pragma unroll
         for (int q = 0; q < NSTAT; ++q) S[q] = 0.0;
@@ -1318,13 +1325,14 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                         if (has_nu(MODEL) && post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
                         if (has_nu(MODEL) && A.tr_nu) A.tr_nu[(size_t)trow * (size_t)A.N * J + e] = nu;     // Post.qr's vec(nu_t) (src/GibbsRtIrtCross.pl.jl:296)
                     }
-                    const real den = r_div(r_sqrt(k2), r_sqrt(isig));            // sqrt(sig2t k2)
-                    const real parA = r_div(r_abs(c - lamc + ze + th * rho), den);
-                    const real parB = r_div(r_sqrt(real(2) * k2 + k1 * k1), den);
                     real nun = real(1);
                     if constexpr (has_nu(MODEL)) {
                         Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i + A.row_base, (uint32_t)j, sweep + 1u);
-                        nun = qr_weight<real>(st, parA, parB, logtab);
+                        if constexpr (sizeof(real) == 8) nun = qr_weight_q(st, fabs(c - lamc + ze + th * rho), qr_cB, qr_lam, logtab);      // parB / parA = cB / |residual|, lambda = parB^2 (per item, hoisted)
+                        else {
+                            const real den = r_div(r_sqrt(k2), r_sqrt(isig));    // sqrt(sig2t k2)
+                            nun = qr_weight<real>(st, r_div(r_abs(c - lamc + ze + th * rho), den), r_div(r_sqrt(real(2) * k2 + k1 * k1), den), logtab);
+                        }
                         A.nu[e] = nun;
                     }
                     real ti;
@@ -1721,6 +1729,7 @@ __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uin
     case 7: v = pg_tail_weight(par0[k], pgtab); break;
     case 8: v = (double)qr_weight<real>(st, (real)par0[k], (real)par1[k]); break;
     case 9: v = (double)ndtri((real)par0[k]); break;
+    case 17: v = qr_weight_q(st, par0[k], par1[k], par1[k] * par1[k], sh_logtab); break;      // the fp64 cell path's form of the quantile weight (parA = par0, parB = par1 at unit scale)
     case 11: v = fm::log(par0[k]); break;           // the cell path's fp64 elementary functions (erm_rng.hpp, namespace fm)
     case 12: v = fm::exp_neg(par0[k]); break;
     case 13: v = fm::sqrt(par0[k]); break;

@@ -268,6 +268,29 @@ template <typename real> __device__ __forceinline__ real qr_weight(Stream& s, re
     return nu;
 }
 
+// The same weight on the fp64 engine's cell path, from range-specialised division / root / reciprocal (the IEEE sequences of the generic form are
+// five divisions and a root: ~170 of its ~290 instructions).  absres = |residual|, cB = sqrt(2 k2 + k1^2), lambda = parB^2: parB / parA = cB / absres
+// whatever the scale sqrt(sig2t k2) both were divided by.  An infinite mean (an exactly zero residual) is replaced by 1e150: the same root, the same
+// branch (x1 -> lambda / y, second root never taken); the draw is clamped into the normal range before its reciprocal.
+__device__ __forceinline__ double invgauss_q(Stream& s, double mu, double lambda, const double2* tab)       // mu in [1e-10, 1e150]
+{
+    const double y = normal_sq_fast(s, tab);
+    const double w = mu * y;
+    const double t = 1.0 + fm::sqrt(1.0 + fm::div(4.0 * lambda, w));
+    const double x1 = fm::div(4.0 * lambda, y * t * t);
+    const double u = uniform<double>(s);
+    return (u >= fm::rcp(1.0 + x1 * fm::rcp(mu))) ? fm::div(mu * mu, x1) : x1;
+}
+__device__ __forceinline__ double qr_weight_q(Stream& s, double absres, double cB, double lambda, const double2* tab)
+{
+    double mu = absres > 1e-140 ? fm::div(cB, absres) : 1e150;
+    mu = mu < 1e-10 ? 1e-10 : (mu > 1e150 ? 1e150 : mu);
+    double x = invgauss_q(s, mu, lambda, tab);
+    x = x < 1e-300 ? 1e-300 : (x > 1e300 ? 1e300 : x);
+    const double nu = fm::rcp(x);
+    return nu < 1e-10 ? 1e-10 : (nu > 1e10 ? 1e10 : nu);
+}
+
 // ---- standard normal quantile -----------------------------------------------------------------
 // fp32: Giles' (2010) single-precision erfinv polynomial (relative error ~1.3e-7), argument formed from p without cancellation.
 __device__ __forceinline__ float giles_erfinv_poly(float w)

@@ -116,6 +116,19 @@ def test_invgauss_and_qr_weight():
     assert np.max(np.abs(d - o) / o) < 1e-10
 
 
+def test_qr_weight_cell_path_form_is_the_same_variate():
+    """The fp64 engine's cell path draws the quantile weight through range-specialised division / root / reciprocal (qr_weight_q: debug sampler 17) with
+    parB / parA = cB / |residual| and lambda = parB^2 hoisted per item; same stream, same law, same variate as the generic form (8) and as the oracle,
+    including exactly zero and denormal-sized residuals (infinite mean -> the Levy limit) and both clamps."""
+    g = np.random.default_rng(12)
+    pa = np.concatenate([np.abs(g.normal(0, 1, N)) + 1e-12, 10.0 ** g.uniform(-12, 3, N), np.zeros(64), np.full(64, 1e-30), np.full(64, 1e-200), np.full(64, 1e8)])
+    pb = np.concatenate([np.full(N, 1.7), np.exp(g.normal(0.5, 0.7, N)), np.full(256, 1.7)])
+    d, o = _dev(17, pa.size, pa, pb), pu.orc_sample(8, pa.size, pa, pb)
+    assert np.all(np.isfinite(d)) and np.all((d >= 1e-10) & (d <= 1e10))
+    assert np.max(np.abs(d - o) / o) < 1e-9
+    assert np.max(np.abs(_dev(8, pa.size, pa, pb) - o) / o) < 1e-9
+
+
 def test_item_level_samplers():
     g = np.random.default_rng(3)
     m, s = g.normal(0.5, 2, N), np.exp(g.normal(-1, 1, N))
