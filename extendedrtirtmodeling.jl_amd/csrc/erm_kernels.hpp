@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         return (int)__builtin_amdgcn_readfirstlane(g);
     };
 #ifndef ERM_PAIRS_F32
-#define ERM_PAIRS_F32 0
+#define ERM_PAIRS_F32 1       // round 3: the fp32 engine takes item pairs too (8-byte loads; fewer address computations per cell): 53.4 -> 52.9 us in an A/B
 #endif
     if (A.mode == 1 && (sizeof(real) == 8 || ERM_PAIRS_F32) && (J & 1) == 0) {
         // fp64 engine, even test lengths: a lane takes PAIRS of neighbouring items (2s, 2s+1), (2(s+W), ...), so that omega and logT come in
@@ -1228,6 +1228,80 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
                 if (A.mode == 1) {
                     llc = -(lmax + fm::log(bprod, logtab));
                     if (fam_rt(MODEL) || fam_lq(MODEL)) llc -= 0.5 * (rtq + (double)ncells * (2.0 * LOG_2PI + lsig0 + lsig1));
+                }
+#pragma unroll
+                for (int q = 0; q < NSTAT; ++q) { S0[q] += __shfl_xor(S0[q], 32, 64); S1[q] += __shfl_xor(S1[q], 32, 64); }
+                if (jv && half == 0) {
+#pragma unroll
+                    for (int q = 0; q < NSTAT; ++q) { acc[q * J + j0] = S0[q]; acc[q * J + j0 + 1] = S1[q]; }
+                }
+                ll += llc;
+            }
+        }
+    }
+    if constexpr (sizeof(real) == 4 && PHASE == 0 && !fam_cq(MODEL)) {
+        // fp32 fast mode, even test lengths: the same item-pair / half-wave mapping (8-byte loads of omega and logT, one address computation and one
+        // theta / zeta load per TWO cells): the phase is VALU-issue-bound, and the one-item-per-lane path below spends as much on addresses, masks
+        // and conversions as on the cells (83 lane-instructions per cell-update against 45 here).  Cell arithmetic in fp32, the four cells of a lane's
+        // batch summed in fp32 and added to the fp64 accumulators once per batch, as everywhere in this mode.
+        if ((J & 1) == 0 && !ERM_DIAG_ON(A, 7)) {
+            p2_done = true;
+            const int half = lane >> 5, l32 = lane & 31;
+            for (int cb = 0; cb * 64 < J; ++cb) {
+                const int j0 = cb * 64 + 2 * l32;
+                const bool jv = j0 < J;
+                const int jc = jv ? j0 : 0;
+                const float a0 = sh_a[jc], a1 = sh_a[jc + 1], b0 = sh_b[jc], b1 = sh_b[jc + 1];
+                const float lamc0 = sh_lamc[jc], lamc1 = sh_lamc[jc + 1], isig0 = sh_isig[jc], isig1 = sh_isig[jc + 1];
+                const float lconst = 2.0f * (float)LOG_2PI + sh_lsig[jc] + sh_lsig[jc + 1];
+                double S0[NSTAT], S1[NSTAT];
+#pragma unroll
+                for (int q = 0; q < NSTAT; ++q) { S0[q] = 0.0; S1[q] = 0.0; }
+                double llc = 0.0;
+                for (int bt = nbatch - 1 - ((nbatch - 1 - wave) % nWaves + nWaves) % nWaves; bt >= 0; bt -= nWaves) {
+                    float thv[2], zev[2]; float2 wv[2], cv[2]; unsigned int yv[2]; bool okv[2];
+                    const int q0 = 4 * bt + 3;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q = q0 - (2 * u + half);
+                        okv[u] = jv && q < nrows_blk;
+                        const int qc = q < nrows_blk ? q : 0;
+                        const unsigned int e = (unsigned int)qc * (unsigned int)J + (unsigned int)jc;
+                        thv[u] = blk_theta[qc];
+                        zev[u] = (MODEL != MLIRT) ? blk_zeta[qc] : 0.0f;
+                        wv[u] = *reinterpret_cast<const float2*>(blk_omega + e);
+                        yv[u] = *reinterpret_cast<const unsigned short*>(blk_Y + e);
+                        if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const float2*>(blk_C + e); else { cv[u].x = 0.0f; cv[u].y = 0.0f; }
+                    }
+                    float bs0[NSTAT], bs1[NSTAT], bl = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < NSTAT; ++q) { bs0[q] = 0.0f; bs1[q] = 0.0f; }
+                    int nrow = 0;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (!okv[u]) continue;
+                        const float th = thv[u], ze = zev[u], th2 = th * th, hth = 0.5f * th;
+                        auto cell = [&](float w, bool y, float c, float a, float b, float lamc, float isig, float* bs) {
+                            bs[0] += w; bs[1] = fmaf(w, th, bs[1]); bs[2] = fmaf(w, th2, bs[2]); bs[3] += y ? hth : -hth;
+                            if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) bs[4] = fmaf(c, ze, bs[4]);
+                            if (A.mode == 1) {
+                                const float eta = a * (th - b);
+                                float t = (y ? eta : 0.0f) - log1pexp_r(eta);
+                                if (fam_rt(MODEL) || fam_lq(MODEL)) {
+                                    const float er = c + ze - lamc;
+                                    t = fmaf(-0.5f * er * er, isig, t);
+                                }
+                                bl += t;
+                            }
+                        };
+                        cell(wv[u].x, (yv[u] & 0xFFu) != 0u, cv[u].x, a0, b0, lamc0, isig0, bs0);
+                        cell(wv[u].y, (yv[u] >> 8) != 0u, cv[u].y, a1, b1, lamc1, isig1, bs1);
+                        ++nrow;
+                    }
+#pragma unroll
+                    for (int q = 0; q < NSTAT; ++q) { S0[q] += (double)bs0[q]; S1[q] += (double)bs1[q]; }
+                    if (A.mode == 1 && (fam_rt(MODEL) || fam_lq(MODEL))) bl = fmaf(-0.5f * (float)nrow, lconst, bl);
+                    llc += (double)bl;
                 }
 #pragma unroll
                 for (int q = 0; q < NSTAT; ++q) { S0[q] += __shfl_xor(S0[q], 32, 64); S1[q] += __shfl_xor(S1[q], 32, 64); }
