@@ -508,13 +508,16 @@ __device__ __forceinline__ bool pg1_attempt_f64(double z, uint32_t w0, uint32_t 
     const float rK = r_rcp(K);
     const float p = (0.5f * PI) * rK * r_exp(-K * t);
     const double u1d = word_to_unif<double>(w1);
-    const float u0 = word_to_unif<float>(w0), u1 = (float)u1d, u2 = word_to_unif<float>(w2), V = word_to_unif<float>(w3);   // u1 with RELATIVE accuracy: its log is used
+    const float u0 = word_to_unif<float>(w0), u2 = word_to_unif<float>(w2), V = word_to_unif<float>(w3);
+    // E = -log u1 in fp64 first: the value needs it anyway, and rounded to fp32 it serves the decisions (no v_log_f32, and E is exact to fp32 rounding)
+    double Ed;
+    if constexpr (TAB) Ed = -fm::log(u1d, tab); else Ed = -fm::log(u1d);
     // (a) tail piece iff u0 (p + q) < p
     const float da = fmaf(u0, p + bin.w, -p);
     const bool tail = da < 0.0f;
     bool uns = !(fabsf(da) > fmaf(2e-5f, p, 5e-6f * bin.w)) || !(z < PG_ZMAX);
     // (b) left proposal kept iff u2 <= e^{g(Z) - M}
-    const float E = -r_log(u1);
+    const float E = (float)Ed;
     const float Z = fmaf(bin.y, E, 1.25f), Z2 = Z * Z;
     const float xl = r_rcp(Z2), dz = Z - bin.x;
     const float thr = r_exp(fmaf(-0.5f * dz, dz, fmaf(-0.5f * zf * zf, xl, -bin.z)));
@@ -527,8 +530,6 @@ __device__ __forceinline__ bool pg1_attempt_f64(double z, uint32_t w0, uint32_t 
     unsure = uns || (ok && fabsf(V - S) <= 1e-6f);
     // the value: tail X = t + E/K, left X = 1/Z^2 with Z = a + E/lam -- E/den or 1/den from ONE reciprocal
     const double PId = 3.14159265358979323846;
-    double Ed;
-    if constexpr (TAB) Ed = -fm::log(u1d, tab); else Ed = -fm::log(u1d);
     const double Zd = fma(cd, Ed, 1.25);
     const double den = tail ? fma(0.5 * z, z, 0.125 * PId * PId) : Zd * Zd;
     const double r = fm::rcp(den);
