@@ -127,6 +127,20 @@ def spawn_ranks(n, argv):
     return 0
 
 
+class _OneLineStdout:
+    """Everything this process -- or a library inside it: RCCL prints a version banner to stdout when its first communicator is made -- writes to
+    stdout goes to stderr instead; emit() writes the ONE JSON line to the real stdout."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.real = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        sys.stdout.flush()
+        os.write(self.real, (line + "\n").encode())
+
+
 def make_data(pkg, model, N, J, F, seed):
     import numpy as np
     Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=F, nIter=10, nChain=1, qRt=0.85)
@@ -380,6 +394,7 @@ def roofline(model, N, J, n_loc, precision, tm):
 def main_farm(args, world_env):
     """`--gpus N` (N > 1): the library's chain farm.  One driving process (rank 0, or the only process); see the module docstring."""
     import numpy as np
+    out_line = _OneLineStdout()
     sys.path.insert(0, ROOT)
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     rank = int(os.environ.get("RANK", "0"))
@@ -402,8 +417,8 @@ def main_farm(args, world_env):
             dist.all_reduce(t)
             tot = float(t.item())
         if rank == 0:
-            print(json.dumps({"metric": "launcher self-test", "mode": "farm", "n_gpus": n_dev, "ranks": world, "rank_sum": tot, "backend": "gloo" if dist is not None else None,
-                              "steps": args.steps}), flush=True)
+            out_line.emit(json.dumps({"metric": "launcher self-test", "mode": "farm", "n_gpus": n_dev, "ranks": world, "rank_sum": tot, "backend": "gloo" if dist is not None else None,
+                                      "steps": args.steps}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -486,7 +501,7 @@ def main_farm(args, world_env):
             out["fp32"] = fp32
         if cfg4 is not None:
             out["configs4_value"], out["configs4_ms_per_step"], out["configs4"] = cfg4["value"], cfg4["ms_per_step"], cfg4
-        print(json.dumps(out), flush=True)
+        out_line.emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -501,6 +516,7 @@ def main():
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np  # noqa: F401
+    out_line = _OneLineStdout()
     sys.path.insert(0, ROOT)
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # the oracle's OpenMP threads must not spin on a shared host
     import __graft_entry__ as ge
@@ -538,7 +554,7 @@ def main():
             dist.all_reduce(t)
             tot = float(t.item())
         if rank == 0:
-            print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "ranks": world, "rank_sum": tot, "backend": backend, "steps": args.steps}), flush=True)
+            out_line.emit(json.dumps({"metric": "launcher self-test", "n_gpus": world, "ranks": world, "rank_sum": tot, "backend": backend, "steps": args.steps}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -641,7 +657,7 @@ def main():
                 out["cpu_baseline_all_cores"] = {"value": cells / sec_mt, "unit": "cell-updates/s", "cores": ncores, "kind": "port",
                                                  "sample": f"{nmt} sweeps, same oracle with OpenMP over subjects/items ({ncores} threads)",
                                                  "s_per_sweep": sec_mt}
-        print(json.dumps(out), flush=True)
+        out_line.emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
