@@ -37,11 +37,10 @@ template <typename real> struct PassArgs {
     double* sum_theta; double* sum_zeta; double* sum_nu;
     real* tr_theta; real* tr_zeta; real* tr_nu;     // [rows][N] (CrossQr's tr_nu: [rows][N][J]) or nullptr
     long long N; long long rows_per_block;          // each workgroup owns rows [b*rpb, (b+1)*rpb)
-    int rows_per_wave;                              // capacity of a wave's theta cache: ceil(rpb / nWaves)
+    int rows_per_wave;                              // sizes the row-sum region of LDS: nWaves * 4 * rows_per_wave >= 4 * rows_per_block values (erm_geometry.hpp)
     int J; int nFeat; int W; int logW; int IPL;
     int mode;             // 0 = prologue (no theta/zeta draws, no LL, no trace), 1 = full sweep pass
     int ngx;              // extra global statistics inserted before the log-likelihood slot (LatentQr sigp_mode 1: the 1/nu-weighted Gram entries)
-    int skew;             // FUSED kernels: subjects taken off wave 0's slice (it runs the structural chain of the tiny step first)
     uint32_t chain; uint64_t seed; double k1, k2;
     int dbg_stop;         // -DERM_DIAG_BUILD only: skip everything after stage k (0 = run everything); ignored by the shipped library
     uint32_t dbg_sweep;   // -DERM_DIAG_BUILD only: 0 = the stop applies to every launch, else only to the launch that draws this sweep
@@ -748,7 +747,7 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
     if constexpr (FUSED) {
         if (wave == 0) {
             // structural chain of this sweep's tiny step on wave 0 while waves 1.. stream their row sums; its results (Sigma_p_t, beta_t,
-            // sum 1/sig2t) are first needed by phase 1 (ii), whose entry waits on sh_ready.  Wave 0 owns fewer subjects (A.skew) to make up.
+            // sum 1/sig2t) are first needed by phase 1 (ii), behind the barrier that ends the row sums; wave 0 joins the row sums (groups from a counter) when it is done.
             tiny_struct<MODEL, 0, 1>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);
             if (lane < 8 + 2 * PMAX) {
                 double v = 0.0;

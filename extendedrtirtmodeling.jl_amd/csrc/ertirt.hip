@@ -369,18 +369,6 @@ template <typename real> struct Engine : EngineBase {
         return 0;
 #endif
     }
-    // subjects taken off wave 0's slice in a fused sweep (it runs the structural chain first).  The LDS caches are sized for
-    // skew >= 0 and at most a wave's share of the workgroup's rows: anything else is clamped.  ERM_SKEW is a tuning knob of the
-    // diagnostic build only.
-    int skew_rows() const {
-        int k = 0;       // (round 2: 2 -- wave 0 used to own its row sums; they are dealt dynamically now and the column phase starts behind a barrier)
-#ifdef ERM_DIAG_BUILD
-        if (const char* e = getenv("ERM_SKEW")) k = atoi(e);
-#endif
-        const int nWaves = block_threads / 64;
-        const int cap = (int)std::max<int64_t>(0, rows_per_block / std::max(1, nWaves));
-        return std::min(std::max(k, 0), cap);
-    }
     PassArgs<real> pass_args(int phase, int mode, bool fz = false) const {
         PassArgs<real> a{};
         a.Y = dY.as<uint8_t>(); a.C = dC.as<real>(); a.omega = dOmega.as<real>(); a.nu = dNu.as<real>(); a.X = dX.as<real>();
@@ -393,7 +381,6 @@ template <typename real> struct Engine : EngineBase {
         a.sum_theta = dSumTheta.as<double>(); a.sum_zeta = dSumZeta.as<double>(); a.sum_nu = dSumNu.as<double>();
         a.tr_theta = dTrTheta.as<real>(); a.tr_zeta = dTrZeta.as<real>(); a.tr_nu = dTrNu.as<real>();
         a.N = N; a.rows_per_block = rows_per_block; a.rows_per_wave = rows_per_wave; a.J = J; a.nFeat = Fk; a.W = W; a.logW = logW; a.IPL = IPL; a.mode = mode; a.ngx = phase == 0 ? ngx() : 0;
-        a.skew = fz ? skew_rows() : 0;
         a.chain = (uint32_t)cfg.chain_id; a.seed = cfg.seed;
         const double q = cfg.q_rt;
         a.k1 = (1.0 - 2.0 * q) / (q * (1.0 - q)); a.k2 = 2.0 / (q * (1.0 - q));   // src/Draw.pl.jl:163-164
