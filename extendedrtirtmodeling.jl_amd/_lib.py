@@ -43,7 +43,7 @@ class erm_config(C.Structure):
     ]
 
 
-FLAG_NO_FUSE, FLAG_NO_GRAPH, FLAG_FARM_FORCE_RCCL = 1, 2, 4
+FLAG_NO_FUSE, FLAG_NO_GRAPH, FLAG_FARM_FORCE_RCCL, FLAG_NO_PERSIST = 1, 2, 4, 8
 
 
 class erm_farm_timing(C.Structure):
@@ -61,7 +61,7 @@ class erm_timing(C.Structure):
     _fields_ = [
         ("run_ms", C.c_double), ("pass_ms_total", C.c_double), ("event_overhead_ms", C.c_double), ("pass_launches", C.c_int64), ("sweeps", C.c_int64),
         ("lanes_per_row", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32), ("lds_bytes", C.c_int32),
-        ("cu_count", C.c_int32), ("reserved", C.c_int32),
+        ("cu_count", C.c_int32), ("persistent", C.c_int32),
     ]
 
 

@@ -48,7 +48,59 @@ template <typename real> struct PassArgs {
     int acc_off;          // byte offset in dynamic LDS of the per-wave item accumulators [nWaves][NSTAT][J], the LAST region of a launch's LDS
     uint32_t row_base;    // subject index of local row 0 in the whole data set (subject-sharded chains; 0 otherwise): the random streams are
                           // addressed by the GLOBAL subject index, so a chain does not depend on how its subjects are spread over devices
+    // PERSIST kernels (small data sets: K sweeps in one launch): both halves of the double buffers, the number of sweeps and the parity of the
+    // first one; the statistics rows travel between the sweeps of a launch as tagged packets (xbuf, see persist_* below), tags tag0+1 .. tag0+nsweeps-1
+    double* parB[2]; Ctl* ctlB[2]; double* gslabB[2];
+    uint32_t nsweeps; uint32_t cur0;
+    unsigned long long* xbuf; uint32_t tag0; unsigned int* tmo;
 };
+
+// Statistics exchange between the sweeps of a PERSIST launch (every workgroup resident: the host launches at most one per compute unit).
+// A grid barrier (arrive on a counter, poll it, acquire, then load the rows) is four dependent trips to memory and measured 4.8 us on 32
+// workgroups -- more than the kernel boundary it replaces.  Instead every 64-bit word of a row carries its own validity: a double travels as two
+// packets {tag : 32 | half : 32}, each ONE 8-byte agent-scope store (atomic by size), and the readers poll the packets themselves: one store trip
+// plus one load trip, no counter, no fence, no ordering between packets needed.  xbuf[parity][workgroup][2 * NS]; a row written after sweep k goes
+// to parity k & 1 with tag tag0 + k + 1.  No workgroup can overwrite a row another still waits for: writing the row of sweep k + 2 takes every
+// workgroup's row of sweep k + 1, which a workgroup writes only after it has read all rows of sweep k.  The spin is bounded: on timeout the
+// launch sets *tmo, runs on with garbage, and erm_run reports it.
+__device__ __forceinline__ void persist_put(unsigned long long* row, int e, double v, uint32_t tag)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+    __hip_atomic_store(row + 2 * e, t | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(row + 2 * e + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// entry e of the sum over all workgroups' rows, in the association of the per-sweep path (group sums of GROUP rows in workgroup order, then the
+// groups in order: the epilogue's group reduction followed by reduce_rows), so that the chain does not depend on the schedule
+__device__ __forceinline__ double persist_get(const unsigned long long* par_rows, int nblocks, int NS, int e, uint32_t tag, unsigned int* tmo)
+{
+    double t = 0.0;
+    unsigned int spins = 0;
+    for (int g0 = 0; g0 < nblocks; g0 += GROUP) {
+        unsigned long long lo[GROUP], hi[GROUP];
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) {
+                const unsigned long long* q = par_rows + (size_t)(g0 + u < nblocks ? g0 + u : g0) * 2 * NS + 2 * e;
+                lo[u] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[u] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) ok = ok && (uint32_t)(lo[u] >> 32) == tag && (uint32_t)(hi[u] >> 32) == tag;
+            if (ok) break;
+            if (++spins > (1u << 20)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        double tg = 0.0;
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+            const double v = __longlong_as_double((long long)((lo[u] & 0xffffffffull) | (hi[u] << 32)));
+            tg += (g0 + u < nblocks) ? v : 0.0;
+        }
+        t += tg;
+    }
+    return t;
+}
 
 // Lanes of ONE wave exchange data through LDS: DS instructions of a wave execute in order, so a compiler-level fence is all
 // that is needed between a phase that writes and a phase that reads.
@@ -605,9 +657,12 @@ __device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* pa
 // launch's group-reduced statistics (T.slab0) and parameter block (T.par), bit-identically; workgroup 0 publishes the results
 // (T.par_out, T.ctl_out, traces).  Inputs and outputs are distinct (double-buffered) allocations, so a workgroup that starts late
 // never sees a half-updated block.  That removes one kernel boundary and the tiny kernel's cold start from every sweep.
-template <int MODEL, typename real, int PHASE, bool FUSED>
-__global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) pass_kernel(PassArgs<real> A, TinyArgs T)
+// PERSIST (FUSED only; small data sets): A.nsweeps sweeps in ONE launch, a packet exchange of the statistics rows between them instead of a kernel boundary; the double buffers
+// alternate inside the launch exactly as consecutive launches alternate them, so the chain is the per-sweep schedule's bit for bit.
+template <int MODEL, typename real, int PHASE, bool FUSED, bool PERSIST = false>
+__global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(MODEL, sizeof(real) == 8)) pass_kernel(PassArgs<real> A, TinyArgs T)
 {
+    static_assert(!PERSIST || (FUSED && PHASE == 0), "persistent launches exist for the fused single-pass sweep only");
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
     // the PG phase hands the workgroup's cells out from ONE dynamic queue (round 2: one queue per wave made the waves of a SIMD finish up to
@@ -670,7 +725,20 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
     const real* __restrict__ gC = A.C;
     const real* __restrict__ gX = A.X;
 
-    uint32_t sweep = A.ctl->sweep, trow = A.ctl->row;
+    const uint32_t n_loop = PERSIST ? A.nsweeps : 1u;
+    uint32_t c_sweep = A.ctl->sweep, c_row = A.ctl->row;        // the chain's counters: read once, carried in registers through a persistent launch
+    const uint32_t c_burn = A.ctl->burn_rows;
+    for (uint32_t ks = 0; ks < n_loop; ++ks) {
+    if constexpr (PERSIST) {
+        const bool odd = ((A.cur0 + ks) & 1u) != 0u;             // selects, not A.parB[pc]: a dynamic index would move the argument struct to scratch
+        double* p_in = odd ? A.parB[1] : A.parB[0];   double* p_out = odd ? A.parB[0] : A.parB[1];
+        Ctl* c_in = odd ? A.ctlB[1] : A.ctlB[0];      Ctl* c_out = odd ? A.ctlB[0] : A.ctlB[1];
+        double* g_in = odd ? A.gslabB[1] : A.gslabB[0]; double* g_out = odd ? A.gslabB[0] : A.gslabB[1];
+        A.par = p_in; A.ctl = c_in; A.gslab = g_out;
+        T.par = p_in; T.par_out = p_out; T.slab0 = g_in; T.ctl = c_in; T.ctl_out = c_out;
+        if (ks > 0) { T.first = 0; stamp(0); }
+    }
+    uint32_t sweep = c_sweep, trow = c_row;
     const double* parsrc = A.par;
     // FUSED only: LDS scratch of the tiny step, appended to the pass layout
     const int NS0 = NSTAT * J + NG;
@@ -685,13 +753,20 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         // ------------------------------------------------------------------------------------------------ this sweep's tiny step
         const int tid = threadIdx.x, nthr = blockDim.x;
         for (int e = tid; e < 2 * PMAX * PMAX; e += nthr) sh_x[e] = T.cst[cst_off_xtx(J) + e];
-        for (int e = tid; e < par_size(J); e += nthr) lp[e] = T.par[e];
         for (int e = tid; e < 3 * J + 2; e += nthr) lcst[e] = T.cst[e];
-        reduce_rows(T.slab0, T.nb0, NS0, st0, tid, nthr);
+        if (!PERSIST || ks == 0) {
+            for (int e = tid; e < par_size(J); e += nthr) lp[e] = T.par[e];
+            reduce_rows(T.slab0, T.nb0, NS0, st0, tid, nthr);
+        } else {
+            // later sweeps of a persistent launch: lp still holds the parameter block this workgroup drew (every workgroup runs the tiny step),
+            // the statistics arrive as packets
+            const unsigned long long* rows = A.xbuf + (size_t)((ks - 1u) & 1u) * gridDim.x * 2 * NS0;
+            for (int e = tid; e < NS0; e += nthr) st0[e] = persist_get(rows, (int)gridDim.x, NS0, e, A.tag0 + ks, A.tmo);
+        }
         __syncthreads();
         stamp(1);
-        const uint32_t prev_row = T.ctl->row;
-        sweep = T.ctl->sweep + 1u;
+        const uint32_t prev_row = c_row;
+        sweep = c_sweep + 1u;
         ERM_DIAG_STOP(A, 30);
         trow = T.first ? prev_row : prev_row + 1u;
         if (writer && tid == 0 && !T.first && T.tr_ll) T.tr_ll[prev_row] = st0[NS0 - 1];    // log-likelihood of the sweep the last pass completed
@@ -720,7 +795,8 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         ERM_DIAG_STOP(A, 31);
         parsrc = lp;
     }
-    const bool post_burn = trow >= A.ctl->burn_rows;
+    const bool post_burn = trow >= c_burn;
+    c_sweep = sweep; c_row = trow;                            // what tiny_publish stores as the next sweep's counters
     int* sh_ready = reinterpret_cast<int*>(sh_struct + 5);      // FUSED: set by wave 0 once sh_struct holds Sigma_p_t, beta_t, sum 1/sig2t
 
     // ---- stage item parameters and structural scalars (stand-alone row pass; a FUSED kernel has done it above)
@@ -1439,7 +1515,15 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         double t = 0.0;
         if (e < NSTAT * J) { for (int w = 0; w < nWaves; ++w) t += sh_acc[(size_t)w * NSTAT * J + e]; }
         else { const int gi = e - NSTAT * J; for (int w = 0; w < nWaves; ++w) t += sh_gacc[(size_t)w * NG + gi]; }
-        __hip_atomic_store(out + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through (sc1) store: no release fence needed
+        if (PERSIST && ks + 1u < n_loop) persist_put(A.xbuf + ((size_t)(ks & 1u) * gridDim.x + blockIdx.x) * 2 * NS, e, t, A.tag0 + ks + 1u);
+        else __hip_atomic_store(out + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through (sc1) store: no release fence needed
+    }
+    if (PERSIST && ks + 1u < n_loop) {
+        // not the launch's last sweep: the next head polls the packets; no ticket, no group rows.  The barrier keeps the head's LDS writes behind
+        // this epilogue's LDS reads.
+        __syncthreads();
+        stamp(13);
+        continue;
     }
     // ---- hierarchical reduction: the LAST workgroup of each group of GROUP consecutive ones to arrive sums the group's slab rows
     // in workgroup order (fixed order => deterministic), so the tiny step reads ceil(grid/GROUP) rows instead of grid rows.
@@ -1478,6 +1562,7 @@ __global__ void __launch_bounds__(max_block_threads(MODEL, sizeof(real) == 8)) p
         }
     }
     stamp(13);
+    }   // sweeps of a persistent launch
 }
 
 

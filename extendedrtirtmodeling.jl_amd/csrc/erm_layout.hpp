@@ -63,6 +63,7 @@ template <int MODEL, int PHASE> struct Stats {
 #ifndef ERM_F64_THREADS_LATENTQR
 #define ERM_F64_THREADS_LATENTQR 768      // LatentQr (fp64 inverse-Gaussian weights in the subject draws): 58 spilled registers at 128 VGPRs, none at 168
 #endif
+constexpr int PERSIST_THREADS = 512;           // launch bound of the persistent (small data set) sweep kernel: 256 VGPRs, no spills around its sweep loop
 ERM_HD constexpr int max_block_threads(int model, bool f64) { return f64 ? (model == LATENTQR ? ERM_F64_THREADS_LATENTQR : ERM_F64_THREADS) : ERM_F32_THREADS; }
 
 constexpr int GROUP = 16;           // workgroups whose slab rows are summed by the last of them to finish

@@ -98,6 +98,10 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// A persistent launch needs all its workgroups resident at once.  Two persistent launches of ONE process on one device (a farm's chains sharing a
+// device, several engines) could each hold some compute units and wait for the other's for ever: they take turns.
+std::mutex g_persist_mu[64];
+
 struct EngineBase {
     erm_config cfg{};
     virtual ~EngineBase() {}
@@ -173,6 +177,8 @@ template <typename real> struct Engine : EngineBase {
     // double-buffered: a fused sweep kernel reads [cur] and writes [1 - cur] (parameter block, counters, group-reduced statistics)
     DevBuf dParB[2], dCtlB[2], dGslab0B[2];
     DevBuf dDbgTs;                                   // ERM_TIMELINE diagnostics
+    DevBuf dXbuf;                                    // persistent launches: packet rows of the statistics exchange
+    uint32_t xtag = 0;                               // last packet tag handed out (tags only grow; the buffer is cleared before they wrap)
     int cur = 0;
     int n_groups = 1;
     // subject sharding (erm_set_shard): this device holds subjects [row_base, row_base + N) of n_total
@@ -182,6 +188,10 @@ template <typename real> struct Engine : EngineBase {
     ncclComm_t comm = nullptr;                                       // ... or RCCL enqueued on the engine's stream
     DevBuf dShardSend, dShardRecv[2];
     bool sharded() const { return exch != nullptr || comm != nullptr; }
+    bool persist = false;                             // small data sets: ONE launch per erm_run (pass_kernel<..., PERSIST>: the statistics rows cross between its sweeps as tagged packets)
+    static constexpr int64_t PERSIST_MAX_CELLS = 1 << 17;      // data sets up to this many cells take the persistent schedule (every stage of a sweep is a 3-5 us latency there)
+    static constexpr int PERSIST_MAX_ITEMS = 128;              // ... of at most this many items (every workgroup polls every workgroup's statistics row: ~5 J doubles each)
+    static constexpr int PERSIST_MAX_GRID = 64;                // ... on at most this many workgroups (every workgroup polls every row; always <= one per CU)
     bool fuse_ok = true;                              // false when the fused kernel's LDS layout cannot fit (very long tests): two kernels per sweep then
     bool fused() const { return !m_cq() && fuse_ok; }  // single-pass models run the tiny step inside the row-pass kernel
     DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
@@ -243,7 +253,7 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&ev0));
         HIPCHK(hipEventCreate(&ev1));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 3 * sizeof(Ctl), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 4 * sizeof(Ctl), hipHostMallocDefault));      // [0] upload, [1], [2] read-back of the two device copies, [3] the grid barrier's timeout word
 
         // ---- geometry (pure host function, CPU-tested: erm_geometry.hpp)
         {
@@ -252,7 +262,21 @@ template <typename real> struct Engine : EngineBase {
             gi.lanes_per_row = cfg.lanes_per_row; gi.block_threads = cfg.block_threads; gi.grid_blocks = cfg.grid_blocks;
             gi.cu_count = cu_count; gi.no_fuse = (cfg.flags & ERM_FLAG_NO_FUSE) != 0;
             std::string msg;
-            if (plan_geometry(gi, G, msg) != 0) return fail(ERM_ERR_ARG, msg);
+            // small data sets (the reference's own sizes): few, full workgroups and ONE persistent launch per erm_run
+            bool want_persist = !m_cq() && !gi.no_fuse && (cfg.flags & ERM_FLAG_NO_PERSIST) == 0 && (int64_t)N * J <= PERSIST_MAX_CELLS && J <= PERSIST_MAX_ITEMS;
+#ifdef ERM_DIAG_BUILD
+            want_persist = false;                       // the stage-timing early returns would strand the other workgroups polling for a row that never comes
+#endif
+            bool planned = false;
+            if (want_persist && cfg.block_threads == 0 && cfg.grid_blocks == 0) {
+                GeomIn gp = gi;
+                gp.block_threads = std::min(PERSIST_THREADS, max_block_threads(cfg.model, gi.f64));
+                gp.grid_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(32, (N + 7) / 8));
+                Geom Gp;
+                if (plan_geometry(gp, Gp, msg) == 0 && Gp.fused && Gp.grid_blocks <= std::min(cu_count, PERSIST_MAX_GRID)) { G = Gp; planned = true; }
+            }
+            if (!planned && plan_geometry(gi, G, msg) != 0) return fail(ERM_ERR_ARG, msg);
+            persist = want_persist && G.fused && G.grid_blocks <= std::min(cu_count, PERSIST_MAX_GRID) && G.block_threads <= PERSIST_THREADS;
             W = G.W; logW = G.logW; IPL = G.IPL; block_threads = G.block_threads; grid_blocks = G.grid_blocks; n_groups = G.n_groups;
             rows_per_block = G.rows_per_block; rows_per_wave = G.rows_per_wave; fuse_ok = G.fused;
             for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = G.lds_pass[ph]; ns[ph] = G.ns[ph]; }
@@ -274,7 +298,11 @@ template <typename real> struct Engine : EngineBase {
         rc |= dCst.alloc((size_t)cst_size(J) * sizeof(double));
         rc |= dSlab0.alloc((size_t)grid_blocks * ns[0] * sizeof(double));
         for (int k = 0; k < 2; ++k) rc |= dGslab0B[k].alloc((size_t)n_groups * ns[0] * sizeof(double));
-        rc |= dGcnt.alloc((size_t)2 * n_groups * sizeof(unsigned int));
+        rc |= dGcnt.alloc(((size_t)2 * n_groups + 2) * sizeof(unsigned int));       // group tickets | timeout word of a persistent launch
+        if (persist) {      // packet rows of the persistent launch's statistics exchange: [parity][workgroup][2 * ns] 64-bit packets, tags start at 1
+            rc |= dXbuf.alloc((size_t)2 * grid_blocks * 2 * ns[0] * sizeof(unsigned long long));
+            if (!rc) HIPCHK(hipMemset(dXbuf.p, 0, dXbuf.bytes));
+        }
         if (m_cq()) { rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double)); rc |= dGslab1.alloc((size_t)n_groups * ns[1] * sizeof(double)); }
         for (int k = 0; k < 2; ++k) rc |= dCtlB[k].alloc(sizeof(Ctl));
         rc |= dSumTheta.alloc((size_t)N * sizeof(double));
@@ -321,7 +349,7 @@ template <typename real> struct Engine : EngineBase {
             H2D(dPgTab.p, tab.data(), tab.size() * sizeof(double));
         }
         timing.lanes_per_row = W; timing.block_threads = block_threads; timing.grid_blocks = grid_blocks;
-        timing.lds_bytes = (int32_t)std::max(lds_pass[0], lds_pass[1]); timing.cu_count = cu_count;
+        timing.lds_bytes = (int32_t)std::max(lds_pass[0], lds_pass[1]); timing.cu_count = cu_count; timing.persistent = persist ? 1 : 0;
         return configure_kernels();
     }
 
@@ -349,6 +377,12 @@ template <typename real> struct Engine : EngineBase {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiny_kernel<M, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, tl));
             if constexpr (!fam_cq(M)) {
                 if (fused()) { if (int rc = check_static_lds<M, 0, true>()) return rc; if (int rc = set_lds_attr<M, 0, true>(fused_lds())) return rc; }
+                if (persist) {
+                    hipFuncAttributes fa;
+                    HIPCHK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&pass_kernel<M, real, 0, true, true>)));
+                    if (fa.sharedSizeBytes > G.lds_static[0]) return fail(ERM_ERR_STATE, "internal: the persistent kernel's static LDS exceeds the planner's figure");
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<M, real, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds()));
+                }
             }
             if constexpr (fam_cq(M)) {
                 if (int rc = check_static_lds<M, 1, false>()) return rc;
@@ -389,6 +423,9 @@ template <typename real> struct Engine : EngineBase {
         a.dbg_ts = dDbgTs.as<unsigned long long>();
         a.row_base = (uint32_t)row_base;
         a.acc_off = fz ? G.acc_off_fused : G.acc_off[phase];     // the accumulators close the launch's dynamic LDS
+        for (int k = 0; k < 2; ++k) { a.parB[k] = dParB[k].template as<double>(); a.ctlB[k] = dCtlB[k].template as<Ctl>(); a.gslabB[k] = dGslab0B[k].template as<double>(); }
+        a.nsweeps = 1u; a.cur0 = (uint32_t)cur;
+        a.xbuf = dXbuf.as<unsigned long long>(); a.tag0 = 0u; a.tmo = dGcnt.as<unsigned int>() + 2 * n_groups;
         return a;
     }
     TinyArgs tiny_args(int mode, int first, bool fz = false) const {
@@ -468,6 +505,7 @@ template <typename real> struct Engine : EngineBase {
             RCCLCHK(g_rccl.CommInitRank(&comm, count, id, rank));
         }
         shard_rank = rank; shard_count = count; n_total = ntot; row_base = base; exch = fn; exch_user = user;
+        persist = false; timing.persistent = 0;          // a sharded sweep exchanges its statistics rows on the host side of every launch
         return 0;
     }
     // one whole sweep of a single-pass model: tiny step + row pass in one launch; reads buffers [cur], writes [1 - cur]
@@ -480,6 +518,20 @@ template <typename real> struct Engine : EngineBase {
         if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; ++n_pass_timed; bracket_launches.push_back(1); }
         cur ^= 1;
         if (sharded()) return shard_exchange(0, a.gslab);     // a.gslab: the group rows this launch wrote
+        return 0;
+    }
+    // nsweeps whole sweeps in ONE launch (small data sets): reads buffers [cur] first, alternates inside the launch, leaves cur where nsweeps single launches would
+    template <int MODEL> int launch_persist(int64_t nsweeps, bool first) {
+        PassArgs<real> a = pass_args(0, 1, true);
+        TinyArgs t = tiny_args(0, first ? 1 : 0, true);
+        a.nsweeps = (uint32_t)nsweeps; a.cur0 = (uint32_t)cur;
+        if (xtag > 0x7fffffffu - (uint32_t)nsweeps) { HIPCHK(hipMemsetAsync(dXbuf.p, 0, dXbuf.bytes, stream)); xtag = 0; }
+        a.tag0 = xtag; xtag += (uint32_t)nsweeps;
+        const bool ev = cfg.profile && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size();
+        if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream));
+        hipLaunchKernelGGL((pass_kernel<MODEL, real, 0, true, true>), dim3(grid_blocks), dim3(block_threads), fused_lds(), stream, a, t);
+        if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; n_pass_timed += nsweeps; bracket_launches.push_back((int)nsweeps); }
+        cur = (int)((cur + nsweeps) & 1);
         return 0;
     }
     template <int MODEL, int STEP> int launch_tiny(int mode, int first) {
@@ -531,6 +583,18 @@ template <typename real> struct Engine : EngineBase {
             if constexpr (fam_cq(MODEL)) { if (int rc = launch_pass<MODEL, 1>(0, false)) return rc; }
         }
         int64_t k = 0;
+        if constexpr (!fam_cq(MODEL)) {
+            if (persist && !sharded() && nsweeps > 0) {
+                // blocks of 2^20 sweeps (packet tags are 32 bits and only grow)
+                for (int64_t done = 0; done < nsweeps; ) {
+                    const int64_t nb = std::min<int64_t>(nsweeps - done, 1 << 20);
+                    if (int rc = launch_persist<MODEL>(nb, done == 0)) return rc;
+                    done += nb;
+                }
+                if (int rc = launch_tiny<MODEL, 0>(1, 0)) return rc;
+                return 0;
+            }
+        }
         if (nsweeps > 0) { if (int rc = enqueue_sweep<MODEL>(true, false)) return rc; k = 1; }
         // (a callback exchange synchronises with the host once per pass and cannot be captured; RCCL's all-gather is a stream operation)
         const bool use_graph = exch == nullptr && (cfg.flags & ERM_FLAG_NO_GRAPH) == 0;
@@ -622,12 +686,21 @@ template <typename real> struct Engine : EngineBase {
         if (calibrate) {   // empty event pairs, once per engine: the bracketing overhead that is subtracted from every timed launch
             for (int k = 0; k < 16; ++k) { HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 2 - 2 * k], stream)); HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 1 - 2 * k], stream)); }
         }
+        // persistent launches of one process take turns on a device (see g_persist_mu); held until the stream has drained
+        std::unique_lock<std::mutex> turn;
+        if (persist && !sharded() && nsweeps > 0) turn = std::unique_lock<std::mutex>(g_persist_mu[(unsigned)cfg.device % 64u]);
         HIPCHK(hipEventRecord(ev0, stream));
         if (int rc = dispatch([&](auto m) -> int { return run_model<decltype(m)::value>(nsweeps); })) return rc;
         HIPCHK(hipEventRecord(ev1, stream));
         HIPCHK(hipGetLastError());
         for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpyAsync(&host_ctl[1 + k], dCtlB[k].p, sizeof(Ctl), hipMemcpyDeviceToHost, stream));
+        unsigned int* h_tmo = reinterpret_cast<unsigned int*>(&host_ctl[3]);
+        *h_tmo = 0u;
+        if (persist) HIPCHK(hipMemcpyAsync(h_tmo, dGcnt.as<unsigned int>() + 2 * n_groups, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        if (turn.owns_lock()) turn.unlock();
+        if (*h_tmo != 0u) return fail(ERM_ERR_STATE, "the persistent sweep kernel timed out waiting for another workgroup's statistics (its workgroups were not all "
+                                                     "resident: another persistent kernel holds the device?); re-create the engine with ERM_FLAG_NO_PERSIST");
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
         timing.run_ms = ms; timing.sweeps = nsweeps; timing.pass_ms_total = 0.0; timing.pass_launches = n_pass_timed;

@@ -68,7 +68,8 @@ typedef struct {
 enum {
     ERM_FLAG_NO_FUSE = 1,          /* two kernels per sweep (stand-alone tiny step + row pass) instead of the fused sweep kernel */
     ERM_FLAG_NO_GRAPH = 2,         /* enqueue every sweep instead of replaying the captured 32-sweep hipGraph */
-    ERM_FLAG_FARM_FORCE_RCCL = 4   /* erm_farm_get_mean reduces over RCCL even when all chains share one device (one-rank communicator; tests) */
+    ERM_FLAG_FARM_FORCE_RCCL = 4,  /* erm_farm_get_mean reduces over RCCL even when all chains share one device (one-rank communicator; tests) */
+    ERM_FLAG_NO_PERSIST = 8        /* small data sets: one launch per sweep instead of ONE persistent launch per erm_run (the statistics cross between its sweeps as tagged packets) */
 };
 
 /* Mirrors InputPara (src/Base.pl.jl:100-115).  NULL members are skipped.  Shapes:
@@ -86,7 +87,8 @@ typedef struct {
     int64_t pass_launches;  /* number of row-pass launches timed */
     int64_t sweeps;         /* sweeps in the last erm_run */
     int32_t lanes_per_row, block_threads, grid_blocks, lds_bytes;
-    int32_t cu_count, reserved;
+    int32_t cu_count;
+    int32_t persistent;     /* 1 = this engine runs erm_run as ONE persistent launch (small data sets; ERM_FLAG_NO_PERSIST turns it off) */
 } erm_timing;
 
 /* Replaces the Gibbs* constructors' allocation of Post and Para (src/GibbsRtIrt.pl.jl:94-104,134-144). */

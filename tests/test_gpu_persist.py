@@ -1,0 +1,78 @@
+"""Small data sets: ONE persistent launch per erm_run (pass_kernel<..., PERSIST>: a grid barrier between the sweeps instead of a kernel boundary).
+The chain is the same chain: at one geometry the persistent schedule, the per-sweep launches (ERM_FLAG_NO_PERSIST) and the per-sweep launches without
+graphs give bit-identical traces; against the oracle the usual fp64 bound holds."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+
+L = pu.ge.load_package()._lib
+GEOM = dict(block_threads=512, grid_blocks=32)
+
+
+def _same(a, b, keys=("ra", "item", "ll", "qr")):
+    return all(np.array_equal(a[k], b[k]) for k in keys if k in a)
+
+
+@pytest.mark.parametrize("model", ["mlirt", "rtirt", "null", "latent", "latentqr"])
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_persistent_launch_is_the_per_sweep_chain(model, precision):
+    Y, logT, X, init, _ = pu.make_problem(model, 1000, 15)
+    T = 45
+    per = pu.run_device(model, Y, logT, X, init, T, precision=precision, **GEOM)
+    assert per["engine"].timing()["persistent"] == 1
+    for flags in (L.FLAG_NO_PERSIST, L.FLAG_NO_PERSIST | L.FLAG_NO_GRAPH):
+        ref = pu.run_device(model, Y, logT, X, init, T, precision=precision, flags=flags, **GEOM)
+        assert ref["engine"].timing()["persistent"] == 0
+        assert _same(per, ref), (model, precision, flags)
+        if model != "mlirt":
+            assert np.array_equal(per["rt"], ref["rt"])
+        for k, v in per["state"].items():
+            assert np.array_equal(np.asarray(v), np.asarray(ref["state"][k])), k
+
+
+def test_default_geometry_of_a_small_data_set_is_persistent_and_matches_the_oracle():
+    d = pu.run_pair("rtirt", 1000, 15, 12)
+    assert d["dev"]["engine"].timing()["persistent"] == 1
+    assert np.max(np.abs(d["dev_ra"] - d["orc"]["ra"]) / (1 + np.abs(d["orc"]["ra"]))) < 1e-8
+
+
+def test_split_runs_continue_the_chain():
+    """erm_run(7) + erm_run(1) + erm_run(12) = erm_run(20): the launch starts from whichever half of the double buffers is current."""
+    Y, logT, X, init, _ = pu.make_problem("rtirt", 600, 10)
+    one = pu.run_device("rtirt", Y, logT, X, init, 20, precision="f64")
+    eng = L.Engine(model=pu.MODELS["rtirt"], n_item=10, n_subj=600, n_feat=3, n_iter=20, n_chain=1, n_burnin=10, cov2one=1, q_rt=0.85, seed=1234, precision=1, trace_mode=1)
+    eng.set_data(Y, logT, X)
+    eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in init.items()})
+    for n in (7, 1, 12):
+        eng.run(n)
+    assert eng.timing()["persistent"] == 1
+    assert np.array_equal(eng.item_trace(), one["item"]) and np.array_equal(eng.trace(L.TRACE_RA), one["ra"])
+
+
+def test_larger_data_sets_and_sharded_chains_keep_the_per_sweep_schedule():
+    Y, logT, X, init, _ = pu.make_problem("rtirt", 20000, 12)      # 240k cells > the persistent limit
+    out = pu.run_device("rtirt", Y, logT, X, init, 4, precision="f64")
+    assert out["engine"].timing()["persistent"] == 0
+    for model in ("cross", "crossqr"):                              # two row passes per sweep with item draws between them: per-sweep launches
+        Y, logT, X, init, _ = pu.make_problem(model, 500, 8)
+        assert pu.run_device(model, Y, logT, X, init, 4, precision="f64")["engine"].timing()["persistent"] == 0
+
+
+def test_two_engines_on_one_device_take_turns():
+    """Two persistent launches at once on one device could each wait for the other's compute units: the library serialises them per device."""
+    import threading
+    Y, logT, X, init, _ = pu.make_problem("mlirt", 1000, 15)
+    ref = pu.run_device("mlirt", Y, logT, X, init, 400, precision="f64", trace_full=False)
+    outs = [None, None]
+
+    def work(k):
+        outs[k] = pu.run_device("mlirt", Y, logT, X, init, 400, precision="f64", trace_full=False)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert all(not t.is_alive() for t in th)
+    for o in outs:
+        assert np.array_equal(o["item"], ref["item"])
