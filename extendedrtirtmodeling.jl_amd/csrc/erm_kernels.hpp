@@ -1141,7 +1141,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         // inside a guard band, or with z >= 8, repeats the attempt through the reference form (a real call).  Round 2's proposal by the
         // inverse normal cdf needed a different 30-70-instruction fp64 evaluation per quantile range and therefore per-wave value queues
         // sorted by piece (four ballot rounds per trip, 64 KB of LDS, scattered 8-byte stores); this form needs none of it.
-        while (__any(active)) {
+        while (__all(active)) {                          // every lane holds a cell (a wave with an idle lane has found the queue empty: the loop below)
 #ifdef ERM_DIAG_BUILD
             ++n_trip; n_att += active ? 1u : 0u;
 #endif
@@ -1166,6 +1166,66 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                     active = c < ncell;
                     if (active) { locate(c, rr, j); th = theta_of(rr); z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); kb = pg_bin_index(z); }
                 } else ++att;
+            }
+        }
+        // The queue is empty (some lane found no cell): the wave's idle lanes now attempt AHEAD for the cells still open.  With n open cells the
+        // wave's lanes form n teams of S = 2^floor(log2(64 / n)); member m of a team makes attempt att + m of its cell (attempts are addressed by
+        // (cell, attempt), so which lane makes one does not matter) and the cell takes the accepted attempt of lowest index -- the draw the
+        // sequential loop would have made, a trip or several earlier.  A small data set has one cell per lane and its PG phase is the longest
+        // rejection chain of the workgroup (about four trips); with teams it is two.  A large one gains its last few trips.
+        for (;;) {
+            const unsigned long long am = __ballot(active);
+            if (am == 0ull) break;
+            const int nact = __popcll(am);
+            int lgS = 0;
+            while ((nact << (lgS + 1)) <= 64) ++lgS;
+            const int S = 1 << lgS;
+            // compact the open cells' lanes: lane k < nact learns the k-th open lane (one forward permute of a full permutation)
+            const int rank_a = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+            const int rank_i = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(~am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)~am, 0u));
+            const int owners = __builtin_amdgcn_ds_permute((active ? rank_a : nact + rank_i) << 2, lane);
+            const int team = lane >> lgS, member = lane & (S - 1);
+            const int own = __builtin_amdgcn_ds_bpermute(team << 2, owners) << 2;
+            const bool work = team < nact;
+            const int rr_h = __builtin_amdgcn_ds_bpermute(own, rr), j_h = __builtin_amdgcn_ds_bpermute(own, j), kb_h = __builtin_amdgcn_ds_bpermute(own, kb);
+            const uint32_t att_h = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)att) + (uint32_t)member;
+            real z_h;
+            if constexpr (sizeof(real) == 8) {
+                const long long zb = __double_as_longlong(z);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)(uint32_t)zb), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)(uint32_t)((unsigned long long)zb >> 32));
+                z_h = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            } else z_h = __int_as_float(__builtin_amdgcn_ds_bpermute(own, __float_as_int(z)));
+#ifdef ERM_DIAG_BUILD
+            ++n_trip; n_att += active ? 1u : 0u;
+#endif
+            bool acc_h = false;
+            real w_h = real(0);
+            if (work) {
+                uint32_t w0, w1, w2, w3;
+                philox4x32_10((uint32_t)(qrow0 + rr_h) + A.row_base, (uint32_t)j_h, sweep + 1u, c3 | att_h, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                bool unsure;
+                if constexpr (sizeof(real) == 8) acc_h = pg1_attempt_f64<true>(z_h, w0, w1, w2, w3, sh_pgf[kb_h], sh_pgc[kb_h], logtab, w_h, unsure);
+                else { acc_h = pg1_attempt(z_h, w0, w1, w2, w3, sh_pgf[kb_h], w_h); unsure = !(z_h < (real)PG_ZMAX); }
+                if (__any(unsure)) {
+                    double o2;
+                    const bool a2 = pg1_attempt_ref_call((double)z_h, w0, w1, w2, w3, A.pgtab, &o2);
+                    if (unsure) { acc_h = a2; w_h = (real)o2; }
+                }
+                acc_h = acc_h || att_h + 1u >= (uint32_t)MAX_TRIES;
+            }
+            const unsigned long long hm = __ballot(acc_h);
+            // the owner reads its team's verdicts: the accepted attempt of lowest index, if any
+            const unsigned long long mine = (hm >> ((rank_a << lgS) & 63)) & (S == 64 ? ~0ull : ((1ull << S) - 1ull));
+            const int src = (((rank_a << lgS) + (mine ? __builtin_ctzll(mine) : 0)) & 63) << 2;
+            real w_o;
+            if constexpr (sizeof(real) == 8) {
+                const long long wb = __double_as_longlong(w_h);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)wb), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)((unsigned long long)wb >> 32));
+                w_o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            } else w_o = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w_h)));
+            if (active) {
+                if (mine) { __hip_atomic_store(om + c, w_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); active = false; }
+                else att += (uint32_t)S;
             }
         }
         if (ERM_DIAG_ON(A, 9)) {

@@ -116,13 +116,15 @@ def test_stage_timing_knobs_do_not_exist_in_the_shipped_library(monkeypatch):
 @pytest.mark.parametrize("model", ["rtirt", "mlirt", "latentqr"])
 def test_schedule_flags_change_the_schedule_not_the_chain(model):
     """erm_config.flags (round 3: schedule switches are config fields, not environment variables): ERM_FLAG_NO_FUSE = stand-alone tiny kernel + row pass
-    instead of the fused sweep kernel, ERM_FLAG_NO_GRAPH = every sweep enqueued instead of the replayed 32-sweep hipGraph.  Same chain: item-level draws
+    instead of the fused sweep kernel, ERM_FLAG_NO_GRAPH = every sweep enqueued instead of the replayed 32-sweep hipGraph, ERM_FLAG_NO_PERSIST = per-sweep launches instead of one
+    persistent launch per erm_run (small data sets).  Same chain: item-level draws
     agree to rounding of the statistics' summation (the fused head and the tiny kernel reduce the same rows in the same order: bit-identical)."""
     Y, logT, X, init, _ = pu.make_problem(model, 900, 9)
     T = 40                                    # long enough for the 32-sweep graph
-    ref = pu.run_device(model, Y, logT, X, init, T, precision="f64")
-    for flags in (L.FLAG_NO_GRAPH, L.FLAG_NO_FUSE, L.FLAG_NO_FUSE | L.FLAG_NO_GRAPH):
-        got = pu.run_device(model, Y, logT, X, init, T, precision="f64", flags=flags)
+    geom = dict(block_threads=512, grid_blocks=32)       # one geometry for every schedule (a data set this small defaults to the persistent launch and ITS geometry)
+    ref = pu.run_device(model, Y, logT, X, init, T, precision="f64", **geom)
+    for flags in (L.FLAG_NO_GRAPH, L.FLAG_NO_PERSIST, L.FLAG_NO_PERSIST | L.FLAG_NO_GRAPH, L.FLAG_NO_FUSE, L.FLAG_NO_FUSE | L.FLAG_NO_GRAPH):
+        got = pu.run_device(model, Y, logT, X, init, T, precision="f64", flags=flags, **geom)
         assert np.array_equal(got["ra"], ref["ra"]) and np.array_equal(got["item"], ref["item"]) and np.array_equal(got["ll"], ref["ll"]), flags
 
 
