@@ -775,7 +775,9 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         // wave 0 starts the pre-barrier part of the structural chain at once (it is the longest strand of the head and needs nothing of
         // this sweep's item draws); in workgroups of 256+ threads it owns no item threads and skips tiny_items altogether
         if (wave == 0) tiny_struct<MODEL, 0, 0>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);
+        stamp(14);
         if (wave != 0 || nthr < 256) tiny_items<MODEL, 0>(T, lp, st0, nullptr, part, work, sweep, lcst);
+        stamp(15);
         // every item thread stages what it has just drawn for the row pass (same thread mapping as tiny_items), so ONE barrier ends the head
         {
             const int ioff = nthr >= 256 ? 128 : 0, nit = nthr - ioff, Jw = (J + 63) & ~63, rt_off = (nit >= 2 * Jw) ? Jw : 0;

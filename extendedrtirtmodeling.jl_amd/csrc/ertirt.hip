@@ -733,16 +733,16 @@ template <typename real> struct Engine : EngineBase {
         if (dDbgTs.p) {      // per-wave phase timeline of the LAST launch (us since the workgroup's first stamp)
             std::vector<unsigned long long> ts(2 * 16 * 16);
             HIPCHK(hipMemcpy(ts.data(), dDbgTs.p, ts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            static const char* names[14] = {"start", "B1", "B3", "struct", "sums", "ready", "draws", "PG", "barrier", "gstats", "phase2", "slab", "ticket", "end"};
+            static const char* names[16] = {"start", "B1", "B3", "struct", "sums", "ready", "draws", "PG", "barrier", "gstats", "phase2", "slab", "ticket", "end", "hd-str0", "hd-item"};
             for (int b = 0; b < 2; ++b) {
                 unsigned long long t0 = ~0ull;
                 for (int w = 0; w < 16; ++w) if (ts[(b * 16 + w) * 16] && ts[(b * 16 + w) * 16] < t0) t0 = ts[(b * 16 + w) * 16];
                 fprintf(stderr, "[erm timeline] workgroup %s\n  wave", b == 0 ? "0" : "grid/2");
-                for (int k = 0; k < 14; ++k) fprintf(stderr, " %7s", names[k]);
+                for (int k = 0; k < 16; ++k) fprintf(stderr, " %7s", names[k]);
                 fprintf(stderr, "\n");
                 for (int w = 0; w < 16; ++w) {
                     fprintf(stderr, "  %4d", w);
-                    for (int k = 0; k < 14; ++k) { const unsigned long long v = ts[(b * 16 + w) * 16 + k]; fprintf(stderr, " %7.2f", v ? (double)(v - t0) * 0.01 : -1.0); }
+                    for (int k = 0; k < 16; ++k) { const unsigned long long v = ts[(b * 16 + w) * 16 + k]; fprintf(stderr, " %7.2f", v ? (double)(v - t0) * 0.01 : -1.0); }
                     fprintf(stderr, "\n");
                 }
             }
