@@ -697,6 +697,36 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
 #endif
     };
     stamp(0);
+    // The launch's inputs are requested in ONE trip: every source's first element per thread is loaded (clamped index, so the loads are
+    // unconditional and the compiler issues them back to back) before anything waits.  As separate load -> wait -> LDS-store loops the head
+    // made six dependent trips to L2 / HBM before its first barrier (3.5 us of a 70 us launch).
+    // the Polya-Gamma proposal table: {lam, 1/lam, M, q} per z-bin rounded to fp32 (decisions), 1/lam in fp64 (the fp64 engine's values);
+    // published by the first barrier below (pass_static_lds() in erm_layout.hpp counts these arrays)
+    [[maybe_unused]] const float4* sh_pgf = nullptr;
+    [[maybe_unused]] const double* sh_pgc = nullptr;
+    [[maybe_unused]] double2 pg_lo = make_double2(0.0, 0.0), pg_hi = make_double2(0.0, 0.0);
+    if constexpr (PHASE == 0) {
+        const double2* b = reinterpret_cast<const double2*>(A.pgtab) + 2 * ((int)threadIdx.x < PG_NBIN ? (int)threadIdx.x : 0);
+        pg_lo = b[0]; pg_hi = b[1];
+    }
+    // FUSED: the (first) sweep's head inputs -- x'x and its inverse, the item constants, the parameter block, the first GROUP group rows of the statistics
+    [[maybe_unused]] double hd_x = 0.0, hd_c = 0.0, hd_p = 0.0, hd_r[16];
+    if constexpr (FUSED) {
+        const int tid = (int)threadIdx.x, NSh = NSTAT * J + NG;
+        const double* par0 = T.par; const double* slab00 = T.slab0;
+        if constexpr (PERSIST) { par0 = (A.cur0 & 1u) ? A.parB[1] : A.parB[0]; slab00 = (A.cur0 & 1u) ? A.gslabB[1] : A.gslabB[0]; }
+        hd_x = T.cst[cst_off_xtx(J) + (tid < 2 * PMAX * PMAX ? tid : 0)];
+        hd_c = T.cst[tid < 3 * J + 2 ? tid : 0];
+        hd_p = par0[tid < par_size(J) ? tid : 0];
+        // (the host allocates at least GROUP rows: rows beyond nb0 are requested too and masked in the sum; per-row clamps cost ~110 scalar
+        // instructions per wave, and the CU's one scalar unit is what the sixteen waves of a starting workgroup queue for)
+        const double* rp = slab00 + (tid < NSh ? tid : 0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) hd_r[u] = rp[(size_t)u * NSh];
+    }
+    uint32_t c_sweep = A.ctl->sweep, c_row = A.ctl->row;        // the chain's counters: read once, carried in registers through a persistent launch
+    const uint32_t c_burn = A.ctl->burn_rows;
+    asm volatile("" ::: "memory");                  // the loads above stay above the table arithmetic below
     // fp64 engine: the 2 KB table of fm::log (filled here; the first barrier below -- the head's, or the staging barrier -- publishes it)
     [[maybe_unused]] const double2* logtab = nullptr;
     if constexpr (sizeof(real) == 8) {
@@ -704,20 +734,18 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         fm::fill_log_table(sh_logtab, (int)threadIdx.x, (int)blockDim.x);
         logtab = sh_logtab;
     }
-    // the Polya-Gamma proposal table: {lam, 1/lam, M, q} per z-bin rounded to fp32 (decisions), 1/lam in fp64 (the fp64 engine's values);
-    // published by the same barrier (pass_static_lds() in erm_layout.hpp counts these arrays)
-    [[maybe_unused]] const float4* sh_pgf = nullptr;
-    [[maybe_unused]] const double* sh_pgc = nullptr;
     if constexpr (PHASE == 0) {
         __shared__ float4 sh_pgf_[PG_NBIN];
-        for (int k = threadIdx.x; k < PG_NBIN; k += blockDim.x) {
+        if ((int)threadIdx.x < PG_NBIN) sh_pgf_[threadIdx.x] = make_float4((float)pg_lo.x, (float)pg_lo.y, (float)pg_hi.x, (float)pg_hi.y);
+        for (int k = (int)threadIdx.x + (int)blockDim.x; k < PG_NBIN; k += blockDim.x) {
             const double* b = A.pgtab + 4 * k;
             sh_pgf_[k] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
         }
         sh_pgf = sh_pgf_;
         if constexpr (sizeof(real) == 8) {
             __shared__ double sh_pgc_[PG_NBIN];
-            for (int k = threadIdx.x; k < PG_NBIN; k += blockDim.x) sh_pgc_[k] = A.pgtab[4 * k + 1];
+            if ((int)threadIdx.x < PG_NBIN) sh_pgc_[threadIdx.x] = pg_lo.y;
+            for (int k = (int)threadIdx.x + (int)blockDim.x; k < PG_NBIN; k += blockDim.x) sh_pgc_[k] = A.pgtab[4 * k + 1];
             sh_pgc = sh_pgc_;
         }
     }
@@ -725,9 +753,44 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     const real* __restrict__ gC = A.C;
     const real* __restrict__ gX = A.X;
 
+    // FUSED only: LDS scratch of the tiny step, appended to the pass layout
+    const int NS0 = NSTAT * J + NG;
+    double* st0 = reinterpret_cast<double*>(sh_val + (((size_t)A.rows_per_block * NV + 1) & ~(size_t)1));   // 8-byte aligned
+    double* part = st0 + NS0;                                   // J doubles (1/sig2t_j)
+    double* work = part + J;
+    double* sh_x = work + TINY_WORK;
+    double* lp = sh_x + 2 * PMAX * PMAX;
+    double* lcst = lp + par_size(J);                            // K0, column means, csq, muLam, sdLam (3J + 2)
+    const bool writer = blockIdx.x == 0;
+    if constexpr (FUSED) {
+        // the head inputs requested at the top of the kernel go to LDS (a persistent launch: its first sweep's; the later ones keep x'x, the
+        // constants and the parameter block in LDS and receive the statistics as packets), then whatever a thread's first element did not
+        // cover (long tests, large grids); the statistics in reduce_rows' order
+        const int tid = threadIdx.x, nthr = blockDim.x;
+        const double* par0 = T.par; const double* slab00 = T.slab0;
+        if constexpr (PERSIST) { par0 = (A.cur0 & 1u) ? A.parB[1] : A.parB[0]; slab00 = (A.cur0 & 1u) ? A.gslabB[1] : A.gslabB[0]; }
+        if (tid < 2 * PMAX * PMAX) sh_x[tid] = hd_x;
+        for (int e = tid + nthr; e < 2 * PMAX * PMAX; e += nthr) sh_x[e] = T.cst[cst_off_xtx(J) + e];
+        if (tid < 3 * J + 2) lcst[tid] = hd_c;
+        for (int e = tid + nthr; e < 3 * J + 2; e += nthr) lcst[e] = T.cst[e];
+        if (tid < par_size(J)) lp[tid] = hd_p;
+        for (int e = tid + nthr; e < par_size(J); e += nthr) lp[e] = par0[e];
+        if (tid < NS0) {
+            double t = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += (u < T.nb0) ? hd_r[u] : 0.0;
+            for (int b0 = 16; b0 < T.nb0; b0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = slab00[(size_t)(b0 + u < T.nb0 ? b0 + u : b0) * NS0 + tid];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t += (b0 + u < T.nb0) ? v[u] : 0.0;
+            }
+            st0[tid] = t;
+        }
+        reduce_rows(slab00, T.nb0, NS0, st0, tid + nthr, nthr);
+    }
     const uint32_t n_loop = PERSIST ? A.nsweeps : 1u;
-    uint32_t c_sweep = A.ctl->sweep, c_row = A.ctl->row;        // the chain's counters: read once, carried in registers through a persistent launch
-    const uint32_t c_burn = A.ctl->burn_rows;
     for (uint32_t ks = 0; ks < n_loop; ++ks) {
     if constexpr (PERSIST) {
         const bool odd = ((A.cur0 + ks) & 1u) != 0u;             // selects, not A.parB[pc]: a dynamic index would move the argument struct to scratch
@@ -740,24 +803,11 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     }
     uint32_t sweep = c_sweep, trow = c_row;
     const double* parsrc = A.par;
-    // FUSED only: LDS scratch of the tiny step, appended to the pass layout
-    const int NS0 = NSTAT * J + NG;
-    double* st0 = reinterpret_cast<double*>(sh_val + (((size_t)A.rows_per_block * NV + 1) & ~(size_t)1));   // 8-byte aligned
-    double* part = st0 + NS0;                                   // J doubles (1/sig2t_j)
-    double* work = part + J;
-    double* sh_x = work + TINY_WORK;
-    double* lp = sh_x + 2 * PMAX * PMAX;
-    double* lcst = lp + par_size(J);                            // K0, column means, csq, muLam, sdLam (3J + 2)
-    const bool writer = blockIdx.x == 0;
     if constexpr (FUSED) {
         // ------------------------------------------------------------------------------------------------ this sweep's tiny step
         const int tid = threadIdx.x, nthr = blockDim.x;
-        for (int e = tid; e < 2 * PMAX * PMAX; e += nthr) sh_x[e] = T.cst[cst_off_xtx(J) + e];
-        for (int e = tid; e < 3 * J + 2; e += nthr) lcst[e] = T.cst[e];
-        if (!PERSIST || ks == 0) {
-            for (int e = tid; e < par_size(J); e += nthr) lp[e] = T.par[e];
-            reduce_rows(T.slab0, T.nb0, NS0, st0, tid, nthr);
-        } else {
+        if (PERSIST && ks > 0) {
+            // (x'x and the item constants are still in LDS: nothing writes them)
             // later sweeps of a persistent launch: lp still holds the parameter block this workgroup drew (every workgroup runs the tiny step),
             // the statistics arrive as packets
             const unsigned long long* rows = A.xbuf + (size_t)((ks - 1u) & 1u) * gridDim.x * 2 * NS0;

@@ -297,7 +297,8 @@ template <typename real> struct Engine : EngineBase {
         for (int k = 0; k < 2; ++k) rc |= dParB[k].alloc((size_t)par_size(J) * sizeof(double));
         rc |= dCst.alloc((size_t)cst_size(J) * sizeof(double));
         rc |= dSlab0.alloc((size_t)grid_blocks * ns[0] * sizeof(double));
-        for (int k = 0; k < 2; ++k) rc |= dGslab0B[k].alloc((size_t)n_groups * ns[0] * sizeof(double));
+        // (at least GROUP rows, zero-filled: the fused head requests its first GROUP group rows unconditionally and masks those beyond n_groups)
+        for (int k = 0; k < 2; ++k) rc |= dGslab0B[k].alloc((size_t)std::max(n_groups, GROUP) * ns[0] * sizeof(double));
         rc |= dGcnt.alloc(((size_t)2 * n_groups + 2) * sizeof(unsigned int));       // group tickets | timeout word of a persistent launch
         if (persist) {      // packet rows of the persistent launch's statistics exchange: [parity][workgroup][2 * ns] 64-bit packets, tags start at 1
             rc |= dXbuf.alloc((size_t)2 * grid_blocks * 2 * ns[0] * sizeof(unsigned long long));
@@ -497,7 +498,7 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipSetDevice(cfg.device));
         const size_t width = (size_t)std::max(std::max(ns[0], ns[1]), 3 * J + PMAX * PMAX + 8);
         if (int rc = dShardSend.alloc(width * sizeof(double))) return rc;
-        for (int k = 0; k < (m_cq() ? 2 : 1); ++k) { if (int rc = dShardRecv[k].alloc(width * (size_t)count * sizeof(double))) return rc; }
+        for (int k = 0; k < (m_cq() ? 2 : 1); ++k) { if (int rc = dShardRecv[k].alloc(width * (size_t)std::max(count, GROUP) * sizeof(double))) return rc; }   // >= GROUP rows: see dGslab0B
         if (rccl_id) {
             if (int rc = g_rccl.load()) return rc;
             ncclUniqueId id;
