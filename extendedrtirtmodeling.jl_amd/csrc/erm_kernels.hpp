@@ -699,30 +699,45 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     stamp(0);
     // The launch's inputs are requested in ONE trip: every source's first element per thread is loaded (clamped index, so the loads are
     // unconditional and the compiler issues them back to back) before anything waits.  As separate load -> wait -> LDS-store loops the head
-    // made six dependent trips to L2 / HBM before its first barrier (3.5 us of a 70 us launch).
+    // made six dependent trips to L2 / HBM before its first barrier.  And the waves SHARE the work by role: the time to that barrier is
+    // instruction issue -- the sixteen waves of a starting workgroup, four to a SIMD, each ran all ~600 instructions of this prologue (3.8 us) --
+    // so the waves that hold an element of the statistics rows (role A) do nothing else, and the others (role B) take the tables, x'x, the item
+    // constants and the parameter block.  Too few waves for that (small workgroups, long tests): every wave does everything, as before.
+    const int tid0 = (int)threadIdx.x, nthr0 = (int)blockDim.x;
+    const int NSh = NSTAT * J + NG;
+    const int kA = FUSED ? (NSh + 63) >> 6 : 0;
+    const bool split = FUSED && nWaves >= kA + 4;
+    const bool roleA = FUSED && (!split || wave < kA);
+    const bool roleB = !split || wave >= kA;
+    const int tB = split ? tid0 - 64 * kA : tid0, nB = split ? nthr0 - 64 * kA : nthr0;       // role B's thread index and count
     // the Polya-Gamma proposal table: {lam, 1/lam, M, q} per z-bin rounded to fp32 (decisions), 1/lam in fp64 (the fp64 engine's values);
     // published by the first barrier below (pass_static_lds() in erm_layout.hpp counts these arrays)
     [[maybe_unused]] const float4* sh_pgf = nullptr;
     [[maybe_unused]] const double* sh_pgc = nullptr;
     [[maybe_unused]] double2 pg_lo = make_double2(0.0, 0.0), pg_hi = make_double2(0.0, 0.0);
-    if constexpr (PHASE == 0) {
-        const double2* b = reinterpret_cast<const double2*>(A.pgtab) + 2 * ((int)threadIdx.x < PG_NBIN ? (int)threadIdx.x : 0);
-        pg_lo = b[0]; pg_hi = b[1];
-    }
     // FUSED: the (first) sweep's head inputs -- x'x and its inverse, the item constants, the parameter block, the first GROUP group rows of the statistics
     [[maybe_unused]] double hd_x = 0.0, hd_c = 0.0, hd_p = 0.0, hd_r[16];
+    [[maybe_unused]] const double* par0 = T.par; [[maybe_unused]] const double* slab00 = T.slab0;
+    if constexpr (PERSIST) { par0 = (A.cur0 & 1u) ? A.parB[1] : A.parB[0]; slab00 = (A.cur0 & 1u) ? A.gslabB[1] : A.gslabB[0]; }
+    if (roleB) {
+        if constexpr (PHASE == 0) {
+            const double2* b = reinterpret_cast<const double2*>(A.pgtab) + 2 * (tB < PG_NBIN ? tB : 0);
+            pg_lo = b[0]; pg_hi = b[1];
+        }
+        if constexpr (FUSED) {
+            hd_x = T.cst[cst_off_xtx(J) + (tB < 2 * PMAX * PMAX ? tB : 0)];
+            hd_c = T.cst[tB < 3 * J + 2 ? tB : 0];
+            hd_p = par0[tB < par_size(J) ? tB : 0];
+        }
+    }
     if constexpr (FUSED) {
-        const int tid = (int)threadIdx.x, NSh = NSTAT * J + NG;
-        const double* par0 = T.par; const double* slab00 = T.slab0;
-        if constexpr (PERSIST) { par0 = (A.cur0 & 1u) ? A.parB[1] : A.parB[0]; slab00 = (A.cur0 & 1u) ? A.gslabB[1] : A.gslabB[0]; }
-        hd_x = T.cst[cst_off_xtx(J) + (tid < 2 * PMAX * PMAX ? tid : 0)];
-        hd_c = T.cst[tid < 3 * J + 2 ? tid : 0];
-        hd_p = par0[tid < par_size(J) ? tid : 0];
-        // (the host allocates at least GROUP rows: rows beyond nb0 are requested too and masked in the sum; per-row clamps cost ~110 scalar
-        // instructions per wave, and the CU's one scalar unit is what the sixteen waves of a starting workgroup queue for)
-        const double* rp = slab00 + (tid < NSh ? tid : 0);
+        if (roleA) {
+            // (the host allocates at least GROUP rows: rows beyond nb0 are requested too and masked in the sum; per-row clamps cost ~110 scalar
+            // instructions per wave)
+            const double* rp = slab00 + (tid0 < NSh ? tid0 : 0);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) hd_r[u] = rp[(size_t)u * NSh];
+            for (int u = 0; u < 16; ++u) hd_r[u] = rp[(size_t)u * NSh];
+        }
     }
     uint32_t c_sweep = A.ctl->sweep, c_row = A.ctl->row;        // the chain's counters: read once, carried in registers through a persistent launch
     const uint32_t c_burn = A.ctl->burn_rows;
@@ -731,21 +746,25 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     [[maybe_unused]] const double2* logtab = nullptr;
     if constexpr (sizeof(real) == 8) {
         __shared__ double2 sh_logtab[128];
-        fm::fill_log_table(sh_logtab, (int)threadIdx.x, (int)blockDim.x);
+        if (roleB) fm::fill_log_table(sh_logtab, tB, nB);
         logtab = sh_logtab;
     }
     if constexpr (PHASE == 0) {
         __shared__ float4 sh_pgf_[PG_NBIN];
-        if ((int)threadIdx.x < PG_NBIN) sh_pgf_[threadIdx.x] = make_float4((float)pg_lo.x, (float)pg_lo.y, (float)pg_hi.x, (float)pg_hi.y);
-        for (int k = (int)threadIdx.x + (int)blockDim.x; k < PG_NBIN; k += blockDim.x) {
-            const double* b = A.pgtab + 4 * k;
-            sh_pgf_[k] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+        if (roleB) {
+            if (tB < PG_NBIN) sh_pgf_[tB] = make_float4((float)pg_lo.x, (float)pg_lo.y, (float)pg_hi.x, (float)pg_hi.y);
+            for (int k = tB + nB; k < PG_NBIN; k += nB) {
+                const double* b = A.pgtab + 4 * k;
+                sh_pgf_[k] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+            }
         }
         sh_pgf = sh_pgf_;
         if constexpr (sizeof(real) == 8) {
             __shared__ double sh_pgc_[PG_NBIN];
-            if ((int)threadIdx.x < PG_NBIN) sh_pgc_[threadIdx.x] = pg_lo.y;
-            for (int k = (int)threadIdx.x + (int)blockDim.x; k < PG_NBIN; k += blockDim.x) sh_pgc_[k] = A.pgtab[4 * k + 1];
+            if (roleB) {
+                if (tB < PG_NBIN) sh_pgc_[tB] = pg_lo.y;
+                for (int k = tB + nB; k < PG_NBIN; k += nB) sh_pgc_[k] = A.pgtab[4 * k + 1];
+            }
             sh_pgc = sh_pgc_;
         }
     }
@@ -766,29 +785,31 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         // the head inputs requested at the top of the kernel go to LDS (a persistent launch: its first sweep's; the later ones keep x'x, the
         // constants and the parameter block in LDS and receive the statistics as packets), then whatever a thread's first element did not
         // cover (long tests, large grids); the statistics in reduce_rows' order
-        const int tid = threadIdx.x, nthr = blockDim.x;
-        const double* par0 = T.par; const double* slab00 = T.slab0;
-        if constexpr (PERSIST) { par0 = (A.cur0 & 1u) ? A.parB[1] : A.parB[0]; slab00 = (A.cur0 & 1u) ? A.gslabB[1] : A.gslabB[0]; }
-        if (tid < 2 * PMAX * PMAX) sh_x[tid] = hd_x;
-        for (int e = tid + nthr; e < 2 * PMAX * PMAX; e += nthr) sh_x[e] = T.cst[cst_off_xtx(J) + e];
-        if (tid < 3 * J + 2) lcst[tid] = hd_c;
-        for (int e = tid + nthr; e < 3 * J + 2; e += nthr) lcst[e] = T.cst[e];
-        if (tid < par_size(J)) lp[tid] = hd_p;
-        for (int e = tid + nthr; e < par_size(J); e += nthr) lp[e] = par0[e];
-        if (tid < NS0) {
-            double t = 0.0;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t += (u < T.nb0) ? hd_r[u] : 0.0;
-            for (int b0 = 16; b0 < T.nb0; b0 += 16) {
-                double v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = slab00[(size_t)(b0 + u < T.nb0 ? b0 + u : b0) * NS0 + tid];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) t += (b0 + u < T.nb0) ? v[u] : 0.0;
-            }
-            st0[tid] = t;
+        if (roleB) {
+            if (tB < 2 * PMAX * PMAX) sh_x[tB] = hd_x;
+            for (int e = tB + nB; e < 2 * PMAX * PMAX; e += nB) sh_x[e] = T.cst[cst_off_xtx(J) + e];
+            if (tB < 3 * J + 2) lcst[tB] = hd_c;
+            for (int e = tB + nB; e < 3 * J + 2; e += nB) lcst[e] = T.cst[e];
+            if (tB < par_size(J)) lp[tB] = hd_p;
+            for (int e = tB + nB; e < par_size(J); e += nB) lp[e] = par0[e];
         }
-        reduce_rows(slab00, T.nb0, NS0, st0, tid + nthr, nthr);
+        if (roleA) {
+            const int nA = split ? 64 * kA : nthr0;
+            if (tid0 < NS0) {
+                double t = 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t += (u < T.nb0) ? hd_r[u] : 0.0;
+                for (int b0 = 16; b0 < T.nb0; b0 += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = slab00[(size_t)(b0 + u < T.nb0 ? b0 + u : b0) * NS0 + tid0];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t += (b0 + u < T.nb0) ? v[u] : 0.0;
+                }
+                st0[tid0] = t;
+            }
+            reduce_rows(slab00, T.nb0, NS0, st0, tid0 + nA, nA);
+        }
     }
     const uint32_t n_loop = PERSIST ? A.nsweeps : 1u;
     for (uint32_t ks = 0; ks < n_loop; ++ks) {
