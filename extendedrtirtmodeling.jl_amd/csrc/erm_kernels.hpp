@@ -135,7 +135,7 @@ constexpr int KB = 4;     // items per lane whose loads are in flight together i
 #ifdef ERM_DIAG_BUILD
 // (with dbg_sweep != 0 the early return applies to that ONE sweep only: every launch before it ran in full, so the truncated launch works on a valid
 // chain state -- tools/stage_budget.sh reads its counters and its duration)
-#define ERM_DIAG_STOP(args, k) do { if ((args).dbg_stop == (k) && ((args).dbg_sweep == 0u || sweep == (args).dbg_sweep)) return; } while (0)
+#define ERM_DIAG_STOP(args, k) do { if ((args).dbg_stop == (k) && ((args).dbg_sweep == 0u || sweep == (args).dbg_sweep)) __builtin_amdgcn_endpgm(); } while (0)
 #define ERM_DIAG_ON(args, k) ((args).dbg_stop == (k))
 #else
 #define ERM_DIAG_STOP(args, k) ((void)0)
@@ -1206,6 +1206,12 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         real* om = A.omega + (size_t)qrow0 * J;
         const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
         [[maybe_unused]] unsigned int n_att = 0, n_trip = 0;
+#ifndef ERM_PG_VKEYS
+#define ERM_PG_VKEYS 8
+#endif
+        constexpr int NVK = PERSIST ? 0 : ERM_PG_VKEYS;          // round keys of the attempts' Philox blocks kept in vector registers (philox4x32_10_vk)
+        uint32_t pgk[NVK > 0 ? NVK : 1];
+        philox_vector_keys<NVK>((uint32_t)A.seed, (uint32_t)(A.seed >> 32), pgk);
         // (letting a wave whose queue ran dry serve other waves' queues was tried: the hardware favours a SIMD's oldest wave, so the
         // four waves of a SIMD finish up to 17 us apart -- but the phase is VALU-throughput-bound, the SIMD is busy until the last
         // one ends either way, and the stealing logic only added instructions: 78.5 vs 75.3 us per sweep)
@@ -1214,13 +1220,13 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         // inside a guard band, or with z >= 8, repeats the attempt through the reference form (a real call).  Round 2's proposal by the
         // inverse normal cdf needed a different 30-70-instruction fp64 evaluation per quantile range and therefore per-wave value queues
         // sorted by piece (four ballot rounds per trip, 64 KB of LDS, scattered 8-byte stores); this form needs none of it.
-        while (__all(active)) {                          // every lane holds a cell (a wave with an idle lane has found the queue empty: the loop below)
-#ifdef ERM_DIAG_BUILD
+        while (PERSIST ? __all(active) : __any(active)) {    // PERSIST: while every lane holds a cell (a wave with an idle lane has found the queue empty: the loop below)
+#ifdef ERM_DIAG_COUNTERS
             ++n_trip; n_att += active ? 1u : 0u;
 #endif
             if (active) {
                 uint32_t w0, w1, w2, w3;
-                philox4x32_10((uint32_t)(qrow0 + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                philox4x32_10_vk<NVK>((uint32_t)(qrow0 + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), pgk, w0, w1, w2, w3);
                 real w;
                 bool acc_, unsure;
                 if constexpr (sizeof(real) == 8) acc_ = pg1_attempt_f64<true>(z, w0, w1, w2, w3, sh_pgf[kb], sh_pgc[kb], logtab, w, unsure);
@@ -1241,11 +1247,14 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 } else ++att;
             }
         }
+        // (persistent launches -- small data sets -- only: in the large-data kernel the second copy of the attempt raised the register pressure of the
+        // loop above, 21 more moves and SGPR reloads per trip, +7 % instructions for one trip saved in twenty-three)
+        if constexpr (PERSIST)
         // The queue is empty (some lane found no cell): the wave's idle lanes now attempt AHEAD for the cells still open.  With n open cells the
         // wave's lanes form n teams of S = 2^floor(log2(64 / n)); member m of a team makes attempt att + m of its cell (attempts are addressed by
         // (cell, attempt), so which lane makes one does not matter) and the cell takes the accepted attempt of lowest index -- the draw the
         // sequential loop would have made, a trip or several earlier.  A small data set has one cell per lane and its PG phase is the longest
-        // rejection chain of the workgroup (about four trips); with teams it is two.  A large one gains its last few trips.
+        // rejection chain of the workgroup (about four trips); with teams it is two.
         for (;;) {
             const unsigned long long am = __ballot(active);
             if (am == 0ull) break;
@@ -1268,7 +1277,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)(uint32_t)zb), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)(uint32_t)((unsigned long long)zb >> 32));
                 z_h = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
             } else z_h = __int_as_float(__builtin_amdgcn_ds_bpermute(own, __float_as_int(z)));
-#ifdef ERM_DIAG_BUILD
+#ifdef ERM_DIAG_COUNTERS
             ++n_trip; n_att += active ? 1u : 0u;
 #endif
             bool acc_h = false;
@@ -1301,11 +1310,13 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 else att += (uint32_t)S;
             }
         }
+#ifdef ERM_DIAG_COUNTERS
         if (ERM_DIAG_ON(A, 9)) {
             Ctl* cw = const_cast<Ctl*>(A.ctl);
             atomicAdd(&cw->dbg_attempts, (unsigned long long)n_att);
             if (lane == 0) { atomicAdd(&cw->dbg_trips, (unsigned long long)n_trip); atomicAdd(&cw->dbg_cells, (unsigned long long)ncell); }
         }
+#endif
     }
     stamp(7);
     ERM_DIAG_STOP(A, 3);

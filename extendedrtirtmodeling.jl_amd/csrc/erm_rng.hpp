@@ -190,6 +190,37 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
+// The same block with its first NV round keys held in VECTOR registers (kv[], filled once by philox_vector_keys) and the rest derived from (k0, k1) as
+// scalars.  The cell loop of the row pass is short of scalar registers: the compiler parks round keys in VGPR lanes and fetches each with a
+// v_readlane_b32 -- a VALU instruction -- every trip (9 of the loop's 174); spare vector registers hold them for nothing.
+template <int NV>
+__device__ __forceinline__ void philox_vector_keys(uint32_t k0, uint32_t k1, uint32_t (&kv)[NV > 0 ? NV : 1])
+{
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        const uint32_t k = (e & 1) ? k1 + (uint32_t)(e >> 1) * 0xBB67AE85u : k0 + (uint32_t)(e >> 1) * 0x9E3779B9u;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kv[e]) : "s"(k));      // opaque: the compiler must not turn the copy back into a scalar
+    }
+}
+template <int NV>
+__device__ __forceinline__ void philox4x32_10_vk(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, const uint32_t (&kv)[NV > 0 ? NV : 1],
+                                                 uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0, n2;
+        if (2 * r < NV) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"((uint32_t)(p1 >> 32)), "v"(c1), "v"(kv[2 * r < NV ? 2 * r : 0]));
+        else asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"((uint32_t)(p1 >> 32)), "v"(c1), "s"(k0));
+        if (2 * r + 1 < NV) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"((uint32_t)(p0 >> 32)), "v"(c3), "v"(kv[2 * r + 1 < NV ? 2 * r + 1 : 0]));
+        else asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"((uint32_t)(p0 >> 32)), "v"(c3), "s"(k1));
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
 struct Stream {
     uint32_t k0, k1, c0, c1, c2, c3;   // c3 holds site/chain in the top 16 bits, block index below
     uint32_t b0, b1, b2, b3;

@@ -11,7 +11,7 @@ for L in "$@"; do
 import csv,glob,sys
 f=sorted(glob.glob(sys.argv[1]+"/*/*counter_collection.csv"))
 if not f: print("no counter file under", sys.argv[1], "(see", sys.argv[1]+".log)"); sys.exit(0)
-v=[float(r["Counter_Value"]) for r in csv.DictReader(open(f[-1])) if ", true>" in r["Kernel_Name"] and r["Counter_Name"]==sys.argv[3]]
+v=[float(r["Counter_Value"]) for r in csv.DictReader(open(f[-1])) if ", true, false>" in r["Kernel_Name"] and r["Counter_Name"]==sys.argv[3]]
 print("%-45s %s %.0f KB per launch" % (sys.argv[2], sys.argv[3], sum(v[2:])/max(1,len(v[2:]))))
 PY
   done

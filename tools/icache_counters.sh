@@ -8,7 +8,7 @@ import csv, glob, collections, os
 f = sorted(glob.glob("gpurun_out/icache/p/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if ", true>" in r["Kernel_Name"]:
+    if ", true, false>" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
     print(k, sum(v[2:]) / max(1, len(v[2:])))

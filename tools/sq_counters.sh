@@ -9,6 +9,6 @@ for d in ("sq","sq2"):
     if not f: print("no file",d); continue
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f[-1])):
-        if ", true>" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if ", true, false>" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in agg.items(): print(k, sum(v[2:])/max(1,len(v[2:])))
 PY

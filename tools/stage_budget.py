@@ -20,7 +20,7 @@ def run(cmd, env, log):
 
 
 def fused_rows(path, name_key):
-    rows = [r for r in csv.DictReader(open(path)) if ", true>" in r[name_key] and "pass_kernel" in r[name_key]]
+    rows = [r for r in csv.DictReader(open(path)) if ", true, false>" in r[name_key] and "pass_kernel" in r[name_key]]
     return rows
 
 

@@ -17,7 +17,7 @@ def one(pattern):
     return f[-1] if f else None
 
 
-def counters(path, kernel=", true>"):      # the fused sweep kernel pass_kernel<MODEL, real, 0, true> (the two non-fused launches are the prologue)
+def counters(path, kernel=", true, false>"):      # the fused sweep kernel pass_kernel<MODEL, real, 0, true, false> (the two non-fused launches are the prologue)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if kernel in r["Kernel_Name"]:
