@@ -616,8 +616,11 @@ __device__ __forceinline__ void tiny_draws(const TinyArgs& T, double* par, const
 // Bookkeeping of one tiny step by ONE workgroup: item-level trace row, finite check, the updated parameter block and the sweep / row
 // counters go to global memory (par_out / ctl_out may alias the inputs when a single workgroup runs the step).
 template <int MODEL, int STEP>
-__device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* par, uint32_t sweep, uint32_t row, int tid, int nthreads)
+__device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* par, uint32_t sweep, uint32_t row, int tid, int nthreads,
+                                             double* par_out = nullptr, Ctl* ctl_out = nullptr, uint32_t burn_rows = 0u)
 {
+    // (a persistent launch passes this sweep's halves of the double buffers and the burn-in row count it carries; otherwise T's)
+    if (!par_out) { par_out = T.par_out; ctl_out = T.ctl_out; burn_rows = T.ctl->burn_rows; }
     const int J = T.J, p = T.nFeat + 1;
     const double* Sigp = par + par_off_sigp(J);
     const double* beta = par + par_off_beta(J);
@@ -637,9 +640,9 @@ __device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* pa
     }
     for (int e = tid; e < par_size(J); e += nthreads) {
         if (!(fabs(par[e]) < 1e300)) atomicCAS(&T.ctl_err->err, 0u, 1u + (uint32_t)e);   // a non-finite entry of the parameter block
-        T.par_out[e] = par[e];
+        par_out[e] = par[e];
     }
-    if (tid == 0 && STEP == 0) { T.ctl_out->sweep = sweep; T.ctl_out->row = row; T.ctl_out->burn_rows = T.ctl->burn_rows; }
+    if (tid == 0 && STEP == 0) { ctl_out->sweep = sweep; ctl_out->row = row; ctl_out->burn_rows = burn_rows; }
 }
 
 
@@ -660,8 +663,9 @@ __device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* pa
 // PERSIST (FUSED only; small data sets): A.nsweeps sweeps in ONE launch, a packet exchange of the statistics rows between them instead of a kernel boundary; the double buffers
 // alternate inside the launch exactly as consecutive launches alternate them, so the chain is the per-sweep schedule's bit for bit.
 template <int MODEL, typename real, int PHASE, bool FUSED, bool PERSIST = false>
-__global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(MODEL, sizeof(real) == 8)) pass_kernel(PassArgs<real> A, TinyArgs T)
+__global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(MODEL, sizeof(real) == 8)) pass_kernel(const PassArgs<real> A_, const TinyArgs T_)
 {
+    const PassArgs<real>& A = A_; const TinyArgs& T = T_;
     static_assert(!PERSIST || (FUSED && PHASE == 0), "persistent launches exist for the fused single-pass sweep only");
     using ST = Stats<MODEL, PHASE>;
     constexpr int NSTAT = ST::NSTAT;
@@ -813,14 +817,24 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     }
     const uint32_t n_loop = PERSIST ? A.nsweeps : 1u;
     for (uint32_t ks = 0; ks < n_loop; ++ks) {
+    // PERSIST, the response-time models: inside the sweep loop the arguments are read through a pointer to the kernel-argument segment that the compiler
+    // cannot see through, so that nothing derived from an argument is hoisted out of the loop and kept (spilled) across it -- every field is an s_load
+    // where it is used.  GibbsRtIrt's kernel: 594 -> 366 spilled SGPRs, 25 -> 0 spilled VGPRs, 1 000 x 15 20.9 -> 18.8 us per sweep.  GibbsMlIrt's has
+    // less to spill and lost 2 % to the loads' latency: it keeps the plain arguments.
+    constexpr bool LAUNDER = PERSIST && MODEL != MLIRT;
+    const char __attribute__((address_space(4)))* kap = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    if constexpr (LAUNDER) asm volatile("" : "+s"(kap));
+    const PassArgs<real>& A = LAUNDER ? *reinterpret_cast<const PassArgs<real>*>((const char*)kap) : A_;
+    const TinyArgs& T = LAUNDER ? *reinterpret_cast<const TinyArgs*>((const char*)kap + ((sizeof(PassArgs<real>) + 7) & ~(size_t)7)) : T_;
+    // this sweep's halves of the double buffers (a persistent launch alternates them as consecutive launches do; A and T themselves stay untouched --
+    // as modified private copies every field of the two argument structs lived in a scalar register for the whole loop: 250 more SGPR spills)
+    double* k_par_out = T.par_out; Ctl* k_ctl_out = T.ctl_out; double* k_gslab_out = A.gslab; int k_first = T.first;
     if constexpr (PERSIST) {
-        const bool odd = ((A.cur0 + ks) & 1u) != 0u;             // selects, not A.parB[pc]: a dynamic index would move the argument struct to scratch
-        double* p_in = odd ? A.parB[1] : A.parB[0];   double* p_out = odd ? A.parB[0] : A.parB[1];
-        Ctl* c_in = odd ? A.ctlB[1] : A.ctlB[0];      Ctl* c_out = odd ? A.ctlB[0] : A.ctlB[1];
-        double* g_in = odd ? A.gslabB[1] : A.gslabB[0]; double* g_out = odd ? A.gslabB[0] : A.gslabB[1];
-        A.par = p_in; A.ctl = c_in; A.gslab = g_out;
-        T.par = p_in; T.par_out = p_out; T.slab0 = g_in; T.ctl = c_in; T.ctl_out = c_out;
-        if (ks > 0) { T.first = 0; stamp(0); }
+        const bool odd = ((A.cur0 + ks) & 1u) != 0u;
+        k_par_out = odd ? A.parB[0] : A.parB[1];
+        k_ctl_out = odd ? A.ctlB[0] : A.ctlB[1];
+        k_gslab_out = odd ? A.gslabB[0] : A.gslabB[1];
+        if (ks > 0) { k_first = 0; stamp(0); }
     }
     uint32_t sweep = c_sweep, trow = c_row;
     const double* parsrc = A.par;
@@ -839,8 +853,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         const uint32_t prev_row = c_row;
         sweep = c_sweep + 1u;
         ERM_DIAG_STOP(A, 30);
-        trow = T.first ? prev_row : prev_row + 1u;
-        if (writer && tid == 0 && !T.first && T.tr_ll) T.tr_ll[prev_row] = st0[NS0 - 1];    // log-likelihood of the sweep the last pass completed
+        trow = k_first ? prev_row : prev_row + 1u;
+        if (writer && tid == 0 && !k_first && T.tr_ll) T.tr_ll[prev_row] = st0[NS0 - 1];    // log-likelihood of the sweep the last pass completed
         // item draws now; the structural chain (beta_t -> Sigma_p_t, ~7 us of dependent fp64 work on one wave) runs on wave 0 AFTER the
         // staging barrier below, concurrently with the other waves' row sums, which do not need it (see `sh_ready`)
         // wave 0 starts the pre-barrier part of the structural chain at once (it is the longest strand of the head and needs nothing of
@@ -907,7 +921,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(sh_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (writer) tiny_publish<MODEL, 0>(T, lp, sweep, trow, lane, 64);
+            if (writer) tiny_publish<MODEL, 0>(T, lp, sweep, trow, lane, 64, k_par_out, k_ctl_out, c_burn);
         }
     }
     stamp(3);
@@ -1209,7 +1223,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
 #ifndef ERM_PG_VKEYS
 #define ERM_PG_VKEYS 8
 #endif
-        constexpr int NVK = PERSIST ? 0 : ERM_PG_VKEYS;          // round keys of the attempts' Philox blocks kept in vector registers (philox4x32_10_vk)
+        constexpr int NVK = PERSIST ? 20 : ERM_PG_VKEYS;         // round keys of the attempts' Philox blocks kept in vector registers (philox4x32_10_vk); the persistent kernel has 256 VGPRs: all twenty
         uint32_t pgk[NVK > 0 ? NVK : 1];
         philox_vector_keys<NVK>((uint32_t)A.seed, (uint32_t)(A.seed >> 32), pgk);
         // (letting a wave whose queue ran dry serve other waves' queues was tried: the hardware favours a SIMD's oldest wave, so the
@@ -1284,7 +1298,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
             real w_h = real(0);
             if (work) {
                 uint32_t w0, w1, w2, w3;
-                philox4x32_10((uint32_t)(qrow0 + rr_h) + A.row_base, (uint32_t)j_h, sweep + 1u, c3 | att_h, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), w0, w1, w2, w3);
+                philox4x32_10_vk<NVK>((uint32_t)(qrow0 + rr_h) + A.row_base, (uint32_t)j_h, sweep + 1u, c3 | att_h, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), pgk, w0, w1, w2, w3);
                 bool unsure;
                 if constexpr (sizeof(real) == 8) acc_h = pg1_attempt_f64<true>(z_h, w0, w1, w2, w3, sh_pgf[kb_h], sh_pgc[kb_h], logtab, w_h, unsure);
                 else { acc_h = pg1_attempt(z_h, w0, w1, w2, w3, sh_pgf[kb_h], w_h); unsure = !(z_h < (real)PG_ZMAX); }
@@ -1694,7 +1708,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     __syncthreads();
     stamp(12);
     if (sh_flag[0]) {
-        double* gout = A.gslab + (size_t)grp * NS;
+        double* gout = k_gslab_out + (size_t)grp * NS;
         for (int e = threadIdx.x; e < NS; e += blockDim.x) {
             double v[GROUP];
 #pragma unroll
