@@ -369,13 +369,41 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
     }
 }
 
+// GibbsRtIrt: covariance of beta_t and its Cholesky factor (drawSubjCoefficients src/Draw.pl.jl:380-393) by ONE wave -- they depend on Sigma_p_{t-1} and
+// the constant (x'x)^-1 only, not on the previous pass's statistics, so a persistent launch has them made by an idle wave while the statistics
+// are still on their way (pass_kernel) instead of at the head of wave 0's chain.  Posterior precision = 11' + kron(inv(Sigp), x'x) (the reference's
+// `1/sigma^2 .+ M` adds 1 to EVERY element), so by Sherman-Morrison parV = Minv - v v'/(1 + 1'v), Minv = kron(Sigp, (x'x)^-1), v = Minv 1.
+// work: V [n*n], L [n*n], tv [n], vv [n], rs [n], pmv [n], zb [n]  (n = 2p)
+__device__ __forceinline__ void rtirt_beta_cov(int p, const double* Sigp, const double* Xinv, double* work, int lane)
+{
+    const int n = 2 * p;
+    double* V = work, *L = V + n * n, *vv = L + n * n + n, *rs = vv + n;
+    if (lane < p) { double t = 0.0; for (int w = 0; w < p; ++w) t += Xinv[lane + w * PMAX]; rs[lane] = t; }
+    wave_sync();
+    if (lane < n) { const int a_ = lane / p, u = lane % p; vv[lane] = (Sigp[a_] + Sigp[a_ + 2]) * rs[u]; }
+    wave_sync();
+    double cden = 1.0;
+    for (int i = 0; i < n; ++i) cden += vv[i];
+    const double icden = q_rcp(cden);
+    for (int e = lane; e < n * n; e += 64) {
+        int i = e % n, jj = e / n;
+        if (i > jj) { const int t_ = i; i = jj; jj = t_; }              // Symmetric(parV): upper triangle
+        const int a_ = i / p, u = i % p, b_ = jj / p, w = jj % p;
+        V[e] = Sigp[a_ + 2 * b_] * Xinv[u + w * PMAX] - vv[i] * vv[jj] * icden;
+    }
+    wave_sync();
+    chol_lower_wave(n, V, L, lane);
+}
+
 // structural draws by ONE wave (lane = its lane index): beta_t (lanes cooperate through LDS), sum_j 1/sig2t_j, Sigma_p_t | beta_t.
 // PART 0: only the leading part of the beta chain, which needs neither the item draws nor Sigma_p's variates (so it can run while
 // other waves draw the items); PART 1: the rest; PART 2: everything.
 template <int MODEL, int STEP, int PART>
 __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, const double* st0, const double* st1, double* part, double* work,
-                                            const double* sh_x, uint32_t sweep, int lane)
+                                            const double* sh_x, uint32_t sweep, int lane, bool have_cov = false, bool have_z = false)
 {
+    // have_cov: GibbsRtIrt's V and L are already in `work` (rtirt_beta_cov by another wave); have_z: beta's standard normals are already in `work`
+    // (zb, drawn by another wave during the head).  Same values either way.
     const double* cstp = T.cst;
     ERM_TINY_COMMON
     const double* XtX = sh_x;                               // p x p, column-major with leading dimension PMAX
@@ -399,38 +427,25 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             // `1/sigma^2 .+ M` adds 1 to EVERY element), so by Sherman-Morrison
             //   parV = Minv - v v'/(1 + 1'v),  Minv = kron(Sigp, (x'x)^-1),  v = Minv 1.
             const int n = 2 * p;
-            double* V = work, *L = V + n * n, *tv = L + n * n, *vv = tv + n, *rs = vv + n, *pmv = rs + n;
+            double* V = work, *L = V + n * n, *tv = L + n * n, *pmv = tv + 3 * n, *zb = pmv + n;
             const double* xt = G0, *xz = G0 + p;
             if (PART != 1) {
+            if (!have_cov) rtirt_beta_cov(p, Sigp, Xinv, work, lane);
             const double s00 = Sigp[0], s10 = Sigp[1], s01 = Sigp[2], s11 = Sigp[3];
             const double isdet = q_rcp(s00 * s11 - s10 * s01);
             const double iO[4] = { s11 * isdet, -s10 * isdet, -s01 * isdet, s00 * isdet };
-            if (lane < p) { double t = 0.0; for (int w = 0; w < p; ++w) t += Xinv[lane + w * PMAX]; rs[lane] = t; }
-            wave_sync();
             if (lane < n) {
                 const int a_ = lane / p, u = lane % p;
-                vv[lane] = (Sigp[a_] + Sigp[a_ + 2]) * rs[u];
                 tv[lane] = 0.0 + xt[u] * iO[a_] + xz[u] * iO[a_ + 2];      // vec(x'eta * inv(Sigp)')
-            }
-            wave_sync();
-            double cden = 1.0;
-            for (int i = 0; i < n; ++i) cden += vv[i];
-            const double icden = q_rcp(cden);
-            for (int e = lane; e < n * n; e += 64) {
-                int i = e % n, jj = e / n;
-                if (i > jj) { const int t_ = i; i = jj; jj = t_; }              // Symmetric(parV): upper triangle
-                const int a_ = i / p, u = i % p, b_ = jj / p, w = jj % p;
-                V[e] = Sigp[a_ + 2 * b_] * Xinv[u + w * PMAX] - vv[i] * vv[jj] * icden;
             }
             wave_sync();
             double pm = 0.0;
             if (lane < n) for (int jj = 0; jj < n; ++jj) pm += V[lane + jj * n] * tv[jj];
-            chol_lower_wave(n, V, L, lane);
             if (lane < n) pmv[lane] = pm;
             }   // ---- part A ends (everything above depends only on the previous pass's statistics and Sigma_p_{t-1})
             if (PART != 0) {
             const double pm = lane < n ? pmv[lane] : 0.0;
-            const double zi = lane < n ? beta_normal(T.seed, T.chain, sweep, lane) : 0.0;     // z_i drawn by lane i
+            const double zi = lane < n ? (have_z ? zb[lane] : beta_normal(T.seed, T.chain, sweep, lane)) : 0.0;     // z_i drawn by lane i
             double t = pm;
             for (int jj = 0; jj < n; ++jj) {
                 const double zj = __shfl(zi, jj, 64);
@@ -492,7 +507,7 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             double pm = 0.0;
             if (lane < q) for (int jj = 0; jj < q; ++jj) pm += Mx[lane + jj * q] * tv[jj];
             chol_lower_wave(q, Mx, L, lane);
-            const double zi = lane < q ? beta_normal(T.seed, T.chain, sweep, lane) : 0.0;
+            const double zi = lane < q ? (have_z ? tv[q + lane] : beta_normal(T.seed, T.chain, sweep, lane)) : 0.0;      // zb = tv + q
             double t = pm;
             for (int jj = 0; jj < q; ++jj) {
                 const double zj = __shfl(zi, jj, 64);
@@ -837,11 +852,19 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         if (ks > 0) { k_first = 0; stamp(0); }
     }
     uint32_t sweep = c_sweep, trow = c_row;
+    [[maybe_unused]] bool have_cov = false;                                     // GibbsRtIrt, later sweeps of a persistent launch: see the head
+    [[maybe_unused]] const bool have_z = FUSED && (MODEL == RTIRT || MODEL == LATENT) && nWaves >= 5;
     const double* parsrc = A.par;
     if constexpr (FUSED) {
         // ------------------------------------------------------------------------------------------------ this sweep's tiny step
         const int tid = threadIdx.x, nthr = blockDim.x;
         if (PERSIST && ks > 0) {
+            // GibbsRtIrt: while waves 0.. wait for the statistics, the last wave makes beta's covariance and its Cholesky factor from Sigma_p_{t-1}
+            // (in lp since the previous sweep) -- 3.5 us that would otherwise head wave 0's chain after the barrier
+            if constexpr (MODEL == RTIRT) {
+                have_cov = nWaves >= 3;
+                if (have_cov && wave == nWaves - 1) rtirt_beta_cov(p, lp + par_off_sigp(J), sh_x + PMAX * PMAX, work, lane);
+            }
             // (x'x and the item constants are still in LDS: nothing writes them)
             // later sweeps of a persistent launch: lp still holds the parameter block this workgroup drew (every workgroup runs the tiny step),
             // the statistics arrive as packets
@@ -859,7 +882,14 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         // staging barrier below, concurrently with the other waves' row sums, which do not need it (see `sh_ready`)
         // wave 0 starts the pre-barrier part of the structural chain at once (it is the longest strand of the head and needs nothing of
         // this sweep's item draws); in workgroups of 256+ threads it owns no item threads and skips tiny_items altogether
-        if (wave == 0) tiny_struct<MODEL, 0, 0>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);
+        // beta's standard normals (GibbsRtIrt: 2p of them, GibbsRtIrtLatent: p + 1) need only the sweep number: wave 4, idle during the head, draws them
+        // into `work` (zb) for wave 0's chain after the barrier
+        if (have_z && wave == 4) {
+            const int nz = MODEL == RTIRT ? 2 * p : p + 1;
+            double* zb = MODEL == RTIRT ? work + 2 * nz * nz + 4 * nz : work + 3 * nz * nz + nz;
+            if (lane < nz) zb[lane] = beta_normal(T.seed, T.chain, sweep, lane);
+        }
+        if (wave == 0) tiny_struct<MODEL, 0, 0>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane, have_cov, have_z);
         stamp(14);
         if (wave != 0 || nthr < 256) tiny_items<MODEL, 0>(T, lp, st0, nullptr, part, work, sweep, lcst);
         stamp(15);
@@ -911,7 +941,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         if (wave == 0) {
             // structural chain of this sweep's tiny step on wave 0 while waves 1.. stream their row sums; its results (Sigma_p_t, beta_t,
             // sum 1/sig2t) are first needed by phase 1 (ii), behind the barrier that ends the row sums; wave 0 joins the row sums (groups from a counter) when it is done.
-            tiny_struct<MODEL, 0, 1>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane);
+            tiny_struct<MODEL, 0, 1>(T, lp, st0, nullptr, part, work, sh_x, sweep, lane, false, have_z);
             if (lane < 8 + 2 * PMAX) {
                 double v = 0.0;
                 if (lane < 4) v = lp[par_off_sigp(J) + lane];
