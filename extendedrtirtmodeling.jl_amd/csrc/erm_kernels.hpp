@@ -853,7 +853,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     }
     uint32_t sweep = c_sweep, trow = c_row;
     [[maybe_unused]] bool have_cov = false;                                     // GibbsRtIrt, later sweeps of a persistent launch: see the head
-    [[maybe_unused]] const bool have_z = FUSED && (MODEL == RTIRT || MODEL == LATENT) && nWaves >= 5;
+    // (persistent launches only: elsewhere wave 0's chain hides behind the other waves' row sums, and the extra block cost the fp32 large-data kernel 0.9 %)
+    [[maybe_unused]] const bool have_z = PERSIST && (MODEL == RTIRT || MODEL == LATENT) && nWaves >= 5;
     const double* parsrc = A.par;
     if constexpr (FUSED) {
         // ------------------------------------------------------------------------------------------------ this sweep's tiny step
