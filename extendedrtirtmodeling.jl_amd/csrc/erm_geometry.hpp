@@ -22,6 +22,7 @@ struct GeomIn {
     int lanes_per_row = 0, block_threads = 0, grid_blocks = 0;      // the caller's overrides, 0 = automatic
     int cu_count = 256;
     bool no_fuse = false;       // diagnostics: keep the two-kernel schedule
+    bool no_persist = false;    // per-sweep launches also for small data sets (ERM_FLAG_NO_PERSIST; sharded chains; the stage-timing build)
 };
 
 struct Geom {
@@ -37,7 +38,14 @@ struct Geom {
     size_t lds_static[2] = {0, 0};              // static LDS of pass_kernel, per pass
     int acc_off[2] = {0, 0}, acc_off_fused = 0; // byte offset of the per-wave item accumulators (the last region of a launch's dynamic LDS)
     int rounds = 1;                             // ceil(grid / resident workgroups)
+    bool persist = false;                       // small data sets: ONE launch per erm_run (pass_kernel<..., PERSIST>), every workgroup resident
 };
+
+// Small data sets -- up to this many cells, of at most this many items (every workgroup polls every workgroup's statistics row: ~5 J doubles each) -- run all
+// sweeps of an erm_run in one persistent launch of at most PERSIST_MAX_GRID workgroups (never more than one per CU) of at most PERSIST_THREADS threads
+constexpr long long PERSIST_MAX_CELLS = 1 << 17;
+constexpr int PERSIST_MAX_ITEMS = 128;
+constexpr int PERSIST_MAX_GRID = 64;
 
 namespace geom_detail {
 inline int nstat(const GeomIn& g, int phase) { return nstat_of(g.model, phase); }
@@ -57,7 +65,7 @@ inline size_t fused_extra(const GeomIn& g) { return 8 + (size_t)(2 * stat_size(g
 }  // namespace geom_detail
 
 // Returns 0 and fills `out`, or -1 with a message (the caller maps it to ERM_ERR_ARG).
-inline int plan_geometry(const GeomIn& g, Geom& out, std::string& err)
+inline int plan_geometry_core(const GeomIn& g, Geom& out, std::string& err)
 {
     using namespace geom_detail;
     const long long N = g.N;
@@ -174,6 +182,27 @@ inline int plan_geometry(const GeomIn& g, Geom& out, std::string& err)
     o.acc_off_fused = fuse ? (int)((o.lds_fused - tail_lds(g, 0, nWaves)) & ~(size_t)7) : 0;
     o.rounds = (int)((gb + slots - 1) / slots);
     out = o;
+    return 0;
+}
+
+// The plan the engine uses: the persistent schedule for small data sets of the single-pass models (its own geometry unless the caller gave one),
+// otherwise the per-sweep plan.
+inline int plan_geometry(const GeomIn& g, Geom& out, std::string& err)
+{
+    const bool cq = g.model == CROSSQR || g.model == CROSS;
+    const bool want = !cq && !g.no_fuse && !g.no_persist && g.N > 0 && g.J > 0 && g.N <= PERSIST_MAX_CELLS && g.N * (long long)g.J <= PERSIST_MAX_CELLS && g.J <= PERSIST_MAX_ITEMS;
+    const int max_grid = std::min(g.cu_count, PERSIST_MAX_GRID);
+    auto fits = [&](const Geom& p) { return p.fused && p.rounds == 1 && p.grid_blocks <= max_grid && p.block_threads <= PERSIST_THREADS; };
+    if (want && g.block_threads == 0 && g.grid_blocks == 0) {
+        GeomIn gp = g;
+        gp.block_threads = std::min(PERSIST_THREADS, max_block_threads(g.model, g.f64));
+        gp.grid_blocks = (int)std::max<long long>(1, std::min<long long>(32, (g.N + 7) / 8));
+        Geom p;
+        std::string e2;
+        if (plan_geometry_core(gp, p, e2) == 0 && fits(p)) { p.persist = true; out = p; return 0; }
+    }
+    if (int rc = plan_geometry_core(g, out, err)) return rc;
+    out.persist = want && fits(out);
     return 0;
 }
 

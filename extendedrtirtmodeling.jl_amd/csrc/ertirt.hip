@@ -189,9 +189,6 @@ template <typename real> struct Engine : EngineBase {
     DevBuf dShardSend, dShardRecv[2];
     bool sharded() const { return exch != nullptr || comm != nullptr; }
     bool persist = false;                             // small data sets: ONE launch per erm_run (pass_kernel<..., PERSIST>: the statistics rows cross between its sweeps as tagged packets)
-    static constexpr int64_t PERSIST_MAX_CELLS = 1 << 17;      // data sets up to this many cells take the persistent schedule (every stage of a sweep is a 3-5 us latency there)
-    static constexpr int PERSIST_MAX_ITEMS = 128;              // ... of at most this many items (every workgroup polls every workgroup's statistics row: ~5 J doubles each)
-    static constexpr int PERSIST_MAX_GRID = 64;                // ... on at most this many workgroups (every workgroup polls every row; always <= one per CU)
     bool fuse_ok = true;                              // false when the fused kernel's LDS layout cannot fit (very long tests): two kernels per sweep then
     bool fused() const { return !m_cq() && fuse_ok; }  // single-pass models run the tiny step inside the row-pass kernel
     DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
@@ -262,21 +259,13 @@ template <typename real> struct Engine : EngineBase {
             gi.lanes_per_row = cfg.lanes_per_row; gi.block_threads = cfg.block_threads; gi.grid_blocks = cfg.grid_blocks;
             gi.cu_count = cu_count; gi.no_fuse = (cfg.flags & ERM_FLAG_NO_FUSE) != 0;
             std::string msg;
-            // small data sets (the reference's own sizes): few, full workgroups and ONE persistent launch per erm_run
-            bool want_persist = !m_cq() && !gi.no_fuse && (cfg.flags & ERM_FLAG_NO_PERSIST) == 0 && (int64_t)N * J <= PERSIST_MAX_CELLS && J <= PERSIST_MAX_ITEMS;
+            // small data sets (the reference's own sizes): few, full workgroups and ONE persistent launch per erm_run -- decided by the planner
+            gi.no_persist = (cfg.flags & ERM_FLAG_NO_PERSIST) != 0;
 #ifdef ERM_DIAG_BUILD
-            want_persist = false;                       // the stage-timing early returns would strand the other workgroups polling for a row that never comes
+            gi.no_persist = true;                       // the stage-timing early exits would strand the other workgroups polling for a row that never comes
 #endif
-            bool planned = false;
-            if (want_persist && cfg.block_threads == 0 && cfg.grid_blocks == 0) {
-                GeomIn gp = gi;
-                gp.block_threads = std::min(PERSIST_THREADS, max_block_threads(cfg.model, gi.f64));
-                gp.grid_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(32, (N + 7) / 8));
-                Geom Gp;
-                if (plan_geometry(gp, Gp, msg) == 0 && Gp.fused && Gp.grid_blocks <= std::min(cu_count, PERSIST_MAX_GRID)) { G = Gp; planned = true; }
-            }
-            if (!planned && plan_geometry(gi, G, msg) != 0) return fail(ERM_ERR_ARG, msg);
-            persist = want_persist && G.fused && G.grid_blocks <= std::min(cu_count, PERSIST_MAX_GRID) && G.block_threads <= PERSIST_THREADS;
+            if (plan_geometry(gi, G, msg) != 0) return fail(ERM_ERR_ARG, msg);
+            persist = G.persist;
             W = G.W; logW = G.logW; IPL = G.IPL; block_threads = G.block_threads; grid_blocks = G.grid_blocks; n_groups = G.n_groups;
             rows_per_block = G.rows_per_block; rows_per_wave = G.rows_per_wave; fuse_ok = G.fused;
             for (int ph = 0; ph < 2; ++ph) { lds_pass[ph] = G.lds_pass[ph]; ns[ph] = G.ns[ph]; }

@@ -1,7 +1,7 @@
 // tests/geometry_check.cpp -- CPU sweep of the launch-geometry planner (extendedrtirtmodeling.jl_amd/csrc/erm_geometry.hpp).
 // Built by tests/test_geometry_planner.py with g++ -fsanitize=undefined -fno-sanitize-recover -ftrapv: any division by zero, signed overflow or
 // out-of-range shift aborts the run.  For every accepted plan it asserts the invariants the kernels rely on; prints a summary and, with
-// `case <model> <f64> <N> <J> <Fk> <bt> <gb> <W> [cus] [nofuse]`, one plan as key=value pairs.
+// `case <model> <f64> <N> <J> <Fk> <bt> <gb> <W> [cus] [nofuse] [nopersist]`, one plan as key=value pairs.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,7 +11,7 @@
 using namespace erm;
 
 #include <map>
-static long long n_ok = 0, n_rej = 0, n_fused = 0, n_auto_rej = 0;
+static long long n_ok = 0, n_rej = 0, n_fused = 0, n_auto_rej = 0, n_persist = 0;
 static std::map<std::string, long long> reasons;
 static int fails = 0;
 #define REQUIRE(cond, ...) do { if (!(cond)) { if (fails++ < 20) { fprintf(stderr, "FAIL %s: ", #cond); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } } while (0)
@@ -63,6 +63,14 @@ static bool check(const GeomIn& g)
         REQUIRE(o.acc_off_fused % 8 == 0 && (size_t)o.acc_off_fused + tail <= o.lds_fused, "%s: acc_off_fused", d);
         REQUIRE((size_t)o.acc_off_fused >= o.lds_pass[0] - tail, "%s: the tiny step's scratch overlaps the pass layout", d);
     }
+    if (o.persist) {
+        // one persistent launch per erm_run: every workgroup resident at once (at most one per CU), 512-thread launch bounds, the fused single-pass sweep
+        ++n_persist;
+        REQUIRE(o.fused && !cq && !g.no_persist && !g.no_fuse, "%s: persistent where it must not be", d);
+        REQUIRE(o.rounds == 1 && o.grid_blocks <= g.cu_count && o.grid_blocks <= PERSIST_MAX_GRID, "%s: persistent grid %d (rounds %d)", d, o.grid_blocks, o.rounds);
+        REQUIRE(o.block_threads <= PERSIST_THREADS, "%s: persistent block of %d threads", d, o.block_threads);
+        REQUIRE(g.N * (long long)g.J <= PERSIST_MAX_CELLS && g.J <= PERSIST_MAX_ITEMS, "%s: persistent beyond its size limits", d);
+    }
     REQUIRE(o.lds_tiny <= LDS_LIMIT, "%s: tiny LDS %zu", d, o.lds_tiny);
     REQUIRE(o.n_groups == (o.grid_blocks + GROUP - 1) / GROUP && o.n_groups <= TINY_THREADS, "%s: n_groups %d", d, o.n_groups);
     REQUIRE(o.W >= 1 && o.W <= 64 && (o.W & (o.W - 1)) == 0 && (1 << o.logW) == o.W && o.IPL * o.W >= g.J, "%s: W %d IPL %d", d, o.W, o.IPL);
@@ -77,11 +85,12 @@ int main(int argc, char** argv)
         g.block_threads = atoi(argv[7]); g.grid_blocks = atoi(argv[8]); g.lanes_per_row = atoi(argv[9]);
         if (argc > 10) g.cu_count = atoi(argv[10]);
         if (argc > 11) g.no_fuse = atoi(argv[11]) != 0;
+        if (argc > 12) g.no_persist = atoi(argv[12]) != 0;
         Geom o; std::string err;
         if (plan_geometry(g, o, err) != 0) { printf("error=%s\n", err.c_str()); return 0; }
         check(g);
-        printf("W=%d block_threads=%d grid_blocks=%d rows_per_block=%lld rows_per_wave=%d fused=%d lds0=%zu lds1=%zu lds_fused=%zu lds_static=%zu rounds=%d n_groups=%d\n", o.W, o.block_threads,
-               o.grid_blocks, o.rows_per_block, o.rows_per_wave, (int)o.fused, o.lds_pass[0], o.lds_pass[1], o.lds_fused, o.lds_static[0], o.rounds, o.n_groups);
+        printf("W=%d block_threads=%d grid_blocks=%d rows_per_block=%lld rows_per_wave=%d fused=%d lds0=%zu lds1=%zu lds_fused=%zu lds_static=%zu rounds=%d n_groups=%d persist=%d\n", o.W, o.block_threads,
+               o.grid_blocks, o.rows_per_block, o.rows_per_wave, (int)o.fused, o.lds_pass[0], o.lds_pass[1], o.lds_fused, o.lds_static[0], o.rounds, o.n_groups, (int)o.persist);
         return fails ? 1 : 0;
     }
     // ---- the sweep
@@ -110,7 +119,8 @@ int main(int argc, char** argv)
                                     for (int nofuse = 0; nofuse <= 1; ++nofuse) {
                                         if (nofuse && (bt || gb || cu != 256)) continue;
                                         g.block_threads = bt; g.grid_blocks = gb; g.cu_count = cu; g.no_fuse = nofuse != 0; g.lanes_per_row = 0;
-                                        check(g);
+                                        g.no_persist = false; check(g);
+                                        if (N * J <= PERSIST_MAX_CELLS) { g.no_persist = true; check(g); }
                                     }
                                 }
                             }
@@ -120,7 +130,7 @@ int main(int argc, char** argv)
     for (int W : {1, 2, 4, 8, 16, 32, 64, 3, 128, -1}) { GeomIn g; g.N = 1000; g.J = 50; g.Fk = 3; g.lanes_per_row = W; check(g); }
     { GeomIn g; g.N = 0; g.J = 5; check(g); g.N = 5; g.J = 0; check(g); g.J = 897; check(g); g.J = 5; g.Fk = 15; check(g); g.Fk = 1; g.block_threads = 100; check(g); g.block_threads = -64; check(g);
       g.block_threads = 0; g.grid_blocks = -1; check(g); g.grid_blocks = 0; g.cu_count = 0; check(g); g.cu_count = 256; g.model = 9; check(g); }
-    printf("plans accepted %lld (fused %lld), rejected %lld (automatic geometry: %lld), invariant failures %d\n", n_ok, n_fused, n_rej, n_auto_rej, fails);
+    printf("plans accepted %lld (fused %lld, persistent %lld), rejected %lld (automatic geometry: %lld), invariant failures %d\n", n_ok, n_fused, n_persist, n_rej, n_auto_rej, fails);
     for (auto& kv : reasons) printf("  rejected %8lld: %s\n", kv.second, kv.first.c_str());
     return fails ? 1 : 0;
 }

@@ -21,8 +21,8 @@ def exe(tmp_path_factory):
     return out
 
 
-def plan(exe, model, f64, N, J, Fk, bt=0, gb=0, W=0, cus=256, nofuse=0):
-    r = subprocess.run([exe, "case"] + [str(v) for v in (model, f64, N, J, Fk, bt, gb, W, cus, nofuse)], capture_output=True, text=True, timeout=60)
+def plan(exe, model, f64, N, J, Fk, bt=0, gb=0, W=0, cus=256, nofuse=0, nopersist=0):
+    r = subprocess.run([exe, "case"] + [str(v) for v in (model, f64, N, J, Fk, bt, gb, W, cus, nofuse, nopersist)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     out = r.stdout.strip()
     if out.startswith("error="):
@@ -77,3 +77,20 @@ def test_headline_geometries(exe):
     assert (p["block_threads"], p["grid_blocks"], p["fused"]) == ("1024", "256", "1")
     p = plan(exe, 1, 1, 500_000, 100, 3)
     assert int(p["grid_blocks"]) > 256 and p["fused"] == "0"
+
+
+def test_small_data_sets_get_the_persistent_schedule(exe):
+    """Round 3: data sets of <= 2^17 cells and <= 128 items run all sweeps of an erm_run in ONE persistent launch: 32 workgroups of 512
+    threads unless the caller gives a geometry, never more workgroups than CUs, only for the fused single-pass models; the per-sweep plan otherwise."""
+    p = plan(exe, 0, 1, 1000, 15, 3)                         # configs[0]: GibbsMlIrt 1000 x 15
+    assert (p["persist"], p["block_threads"], p["grid_blocks"], p["fused"], p["rounds"]) == ("1", "512", "32", "1", "1")
+    assert plan(exe, 1, 0, 1000, 15, 3)["persist"] == "1" and plan(exe, 3, 1, 2000, 15, 3)["persist"] == "1"
+    assert plan(exe, 1, 1, 30, 5, 3)["persist"] == "1" and int(plan(exe, 1, 1, 30, 5, 3)["grid_blocks"]) <= 4
+    assert plan(exe, 1, 1, 1000, 15, 3, nopersist=1)["persist"] == "0"          # ERM_FLAG_NO_PERSIST, sharded chains
+    assert plan(exe, 1, 1, 1000, 15, 3, nofuse=1)["persist"] == "0"
+    assert plan(exe, 2, 1, 1000, 15, 0)["persist"] == "0" and plan(exe, 5, 1, 1000, 15, 0)["persist"] == "0"      # two passes per sweep
+    assert plan(exe, 1, 1, 100_000, 50, 3)["persist"] == "0" and plan(exe, 1, 1, 20_000, 12, 3)["persist"] == "0"   # beyond 2^17 cells
+    assert plan(exe, 1, 1, 500, 200, 3)["persist"] == "0"                       # beyond 128 items
+    assert plan(exe, 1, 1, 1000, 15, 3, bt=512, gb=32)["persist"] == "1"       # an explicit geometry that qualifies
+    assert plan(exe, 1, 1, 1000, 15, 3, bt=1024, gb=32)["persist"] == "0" and plan(exe, 1, 1, 1000, 15, 3, bt=256, gb=125)["persist"] == "0"
+    assert int(plan(exe, 1, 1, 1000, 15, 3, cus=8)["grid_blocks"]) <= 8 or plan(exe, 1, 1, 1000, 15, 3, cus=8)["persist"] == "0"
