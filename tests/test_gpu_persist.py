@@ -76,3 +76,17 @@ def test_two_engines_on_one_device_take_turns():
     assert all(not t.is_alive() for t in th)
     for o in outs:
         assert np.array_equal(o["item"], ref["item"])
+
+
+def test_persistent_runs_are_reproducible_over_long_chains():
+    """The packet exchange has no barrier to hide a race behind: 300-sweep chains in one launch, repeated, bit for bit against the per-sweep chain
+    (tools/persist_stress.py is the long form: 1 200 runs over six shapes and both precisions, no mismatch)."""
+    for model, N, J in (("rtirt", 1000, 15), ("latent", 250, 100), ("mlirt", 37, 5)):
+        Y, logT, X, init, _ = pu.make_problem(model, N, J)
+        per = pu.run_device(model, Y, logT, X, init, 300, precision="f64", trace_full=False)
+        tm = per["engine"].timing()
+        assert tm["persistent"] == 1
+        ref = pu.run_device(model, Y, logT, X, init, 300, precision="f64", trace_full=False, flags=L.FLAG_NO_PERSIST, block_threads=tm["block_threads"], grid_blocks=tm["grid_blocks"])
+        for _ in range(6):
+            got = pu.run_device(model, Y, logT, X, init, 300, precision="f64", trace_full=False)
+            assert np.array_equal(got["item"], ref["item"]) and np.array_equal(got["ll"], ref["ll"]), (model, N, J)
