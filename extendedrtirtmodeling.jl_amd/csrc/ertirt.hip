@@ -533,7 +533,10 @@ template <typename real> struct Engine : EngineBase {
     // One sweep = tiny step + row pass (CrossQr: two of each).  Kernel arguments never change between sweeps (sweep / trace-row
     // counters live in device memory), so a block of GRAPH_SWEEPS sweeps is captured once into a hipGraph and replayed; this
     // removes the per-launch host overhead that otherwise leaves the GPU idle between the short kernels.
-    static constexpr int GRAPH_SWEEPS = 32;
+#ifndef ERM_GRAPH_SWEEPS
+#define ERM_GRAPH_SWEEPS 32
+#endif
+    static constexpr int GRAPH_SWEEPS = ERM_GRAPH_SWEEPS;
     static constexpr int PROFILE_STRIDE = 8;
     static constexpr int TAIL_SWEEPS = 4;            // a second, short graph for the remainder of a run (both counts are even: buffer parity)
     static constexpr int MID_SWEEPS = 16;            // profile mode: the bracketed unit of a short run (a benchmark of a few dozen steps)
