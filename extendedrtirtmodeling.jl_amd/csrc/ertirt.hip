@@ -250,7 +250,7 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&ev0));
         HIPCHK(hipEventCreate(&ev1));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 4 * sizeof(Ctl), hipHostMallocDefault));      // [0] upload, [1], [2] read-back of the two device copies, [3] the grid barrier's timeout word
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 4 * sizeof(Ctl), hipHostMallocDefault));      // [0] upload, [1], [2] read-back of the two device copies, [3] a persistent launch's time-out word
 
         // ---- geometry (pure host function, CPU-tested: erm_geometry.hpp)
         {
