@@ -1613,6 +1613,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
             real bs[NSTAT]; real bl = real(0);
             // fp64: sum_u log(1 + e^{-|eta_u|}) of a batch = log prod_u (1 + e^{-|eta_u|}) -- one logarithm per four cells (each factor is in (1, 2])
             [[maybe_unused]] double bprod = 1.0;
+            [[maybe_unused]] double vprod = 1.0;         // pass B, fp64: product of the batch's k2 nu (the RT log-likelihood's log-variance terms)
 #pragma unroll
             for (int q = 0; q < NSTAT; ++q) bs[q] = real(0);
 #pragma unroll
@@ -1656,7 +1657,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                         const real var_ = k2 * nu;                               // times sig2t_j
                         const real er = c - lamc + ze + th * rho - k1 * nu;    // logT - mu_t
                         real lv;
-                        if constexpr (sizeof(real) == 8) lv = fm::log(var_, logtab); else lv = r_log(var_);       // var_ = k2 nu in [1e-10 k2, 1e10 k2]
+                        if constexpr (sizeof(real) == 8) { lv = real(0); vprod *= var_; }       // fp64: ONE logarithm per batch of four cells, of the product (each factor in [1e-10 k2, 1e10 k2])
+                        else lv = r_log(var_);
                         real qv;
                         if constexpr (sizeof(real) == 8) qv = fm::div(er * er * isig, var_); else qv = r_div(er * er * isig, var_);       // var_ is a normal, finite number
                         bl += real(-0.5) * ((real)LOG_2PI + lsig + lv + qv);
@@ -1682,6 +1684,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
 #pragma unroll
             for (int q = 0; q < NSTAT; ++q) S[q] += (double)bs[q];
             if constexpr (sizeof(real) == 8 && PHASE == 0) { if (A.mode == 1) bl -= fm::log(bprod, logtab); }
+            if constexpr (sizeof(real) == 8 && PHASE == 1) { if (A.mode == 1) bl -= 0.5 * fm::log(vprod, logtab); }
             llc += (double)bl;
         }
         if (jv) {
