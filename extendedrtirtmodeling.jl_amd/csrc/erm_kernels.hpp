@@ -1777,11 +1777,61 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     double* sh_x = work + TINY_WORK;                        // x'x and its inverse (2 * PMAX * PMAX), staged once
     double* lp = sh_x + 2 * PMAX * PMAX;                    // the parameter block, updated in place and written back at the end
     const int tid = threadIdx.x;
-    if (tid < 2 * PMAX * PMAX) sh_x[tid] = T.cst[cst_off_xtx(T.J) + tid];
-    for (int e = tid; e < par_size(J); e += TINY_THREADS) lp[e] = T.par[e];
-
-    reduce_rows(T.slab0, T.nb0, NS0, st0, tid, TINY_THREADS);
-    if (fam_cq(MODEL) && STEP == 0) reduce_rows(T.slab1, T.nb1, NS1, st1, tid, TINY_THREADS);
+    // every input's first elements are requested before anything waits (as separate load -> wait -> store loops the kernel made six dependent trips to
+    // L2 / HBM, half of its 7 us): two elements per thread of x'x | its inverse, of the parameter block and of the statistics of pass A, one of pass
+    // B's; GROUP group rows each (the host allocates at least GROUP rows; those beyond nb are masked in the sum); reduce_rows' order
+    constexpr int TT = TINY_THREADS;
+    constexpr bool HAS1 = fam_cq(MODEL) && STEP == 0;
+    const int nx = 2 * PMAX * PMAX, npar = par_size(J);
+    const double* cx = T.cst + cst_off_xtx(J);
+    const double x0 = cx[tid < nx ? tid : 0], x1 = cx[tid + TT < nx ? tid + TT : 0];
+    const double p0 = T.par[tid < npar ? tid : 0], p1 = T.par[tid + TT < npar ? tid + TT : 0];
+    double ra[GROUP], rb[GROUP], rc[GROUP];
+    const int w0 = tid & ~63;                                // (whole waves skip what none of their lanes needs: sixteen waves issuing 50 loads each is the kernel's time)
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) { ra[u] = 0.0; rb[u] = 0.0; rc[u] = 0.0; }
+    if (w0 < NS0) {
+        const double* qa = T.slab0 + (tid < NS0 ? tid : 0);
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) ra[u] = qa[(size_t)u * NS0];
+    }
+    if (w0 + TT < NS0) {
+        const double* qb = T.slab0 + (tid + TT < NS0 ? tid + TT : 0);
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) rb[u] = qb[(size_t)u * NS0];
+    }
+    if (HAS1 && w0 < NS1) {
+        const double* qc = T.slab1 + (tid < NS1 ? tid : 0);
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) rc[u] = qc[(size_t)u * NS1];
+    }
+    if (tid < nx) sh_x[tid] = x0;
+    if (tid + TT < nx) sh_x[tid + TT] = x1;
+    for (int e = tid + 2 * TT; e < nx; e += TT) sh_x[e] = cx[e];
+    if (tid < npar) lp[tid] = p0;
+    if (tid + TT < npar) lp[tid + TT] = p1;
+    for (int e = tid + 2 * TT; e < npar; e += TT) lp[e] = T.par[e];
+    auto finish = [&](const double (&r)[GROUP], const double* slab, int nb, int NS, int e, double* out) {
+        if (e >= NS) return;
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) t += (u < nb) ? r[u] : 0.0;
+        for (int b0 = GROUP; b0 < nb; b0 += GROUP) {
+            double v[GROUP];
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) v[u] = slab[(size_t)(b0 + u < nb ? b0 + u : b0) * NS + e];
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) t += (b0 + u < nb) ? v[u] : 0.0;
+        }
+        out[e] = t;
+    };
+    finish(ra, T.slab0, T.nb0, NS0, tid, st0);
+    finish(rb, T.slab0, T.nb0, NS0, tid + TT, st0);
+    reduce_rows(T.slab0, T.nb0, NS0, st0, tid + 2 * TT, TT);
+    if constexpr (HAS1) {
+        finish(rc, T.slab1, T.nb1, NS1, tid, st1);
+        reduce_rows(T.slab1, T.nb1, NS1, st1, tid + TT, TT);
+    }
     __syncthreads();
 
     const uint32_t prev_row = T.ctl->row;

@@ -293,7 +293,7 @@ template <typename real> struct Engine : EngineBase {
             rc |= dXbuf.alloc((size_t)2 * grid_blocks * 2 * ns[0] * sizeof(unsigned long long));
             if (!rc) HIPCHK(hipMemset(dXbuf.p, 0, dXbuf.bytes));
         }
-        if (m_cq()) { rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double)); rc |= dGslab1.alloc((size_t)n_groups * ns[1] * sizeof(double)); }
+        if (m_cq()) { rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double)); rc |= dGslab1.alloc((size_t)std::max(n_groups, GROUP) * ns[1] * sizeof(double)); }      // >= GROUP rows: see dGslab0B
         for (int k = 0; k < 2; ++k) rc |= dCtlB[k].alloc(sizeof(Ctl));
         rc |= dSumTheta.alloc((size_t)N * sizeof(double));
         rc |= dSumZeta.alloc((size_t)N * sizeof(double));
