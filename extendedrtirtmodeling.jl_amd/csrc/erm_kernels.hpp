@@ -1368,6 +1368,50 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     __syncthreads();
     stamp(8);
 
+    // ---------------- CrossQr pass B: nu_{t+1} for every cell (src/Draw.pl.jl:303-320) -- and, with nu_t still in hand, the cell's RT log-likelihood
+    // term and the nu traces -- over the workgroup's FLATTENED cells, like the PG phase (cell c = subject row0 + c / J, item c % J = its offset in
+    // the row-major slice: coalesced).  The column phase below keeps one lane per item for its register accumulators, which leaves 14 of 64 lanes idle
+    // at 50 items; this is the expensive part of the pass (an inverse-Gaussian draw: ~90 instructions per cell) and needs no accumulator per item.
+    // (fp64 engine only: in fp32 the draw is a handful of hardware transcendentals and the extra pass over C and nu cost more than the idle lanes: 106.7 -> 109.9 us)
+    constexpr bool NU_FLAT = MODEL == CROSSQR && PHASE == 1 && sizeof(real) == 8;
+    if constexpr (NU_FLAT) {
+        const int ncell = nrows_blk * J;
+        const float invJ = 1.0f / (float)J;
+        const double qr_cB = sqrt((double)(real(2) * k2 + k1 * k1));
+        double llf = 0.0;
+        for (int c = (int)threadIdx.x; c < ncell; c += (int)blockDim.x) {
+            int rr = (int)(((float)c + 0.5f) * invJ);
+            int j = c - rr * J;
+            if (j < 0) { j += J; --rr; } else if (j >= J) { j -= J; ++rr; }
+            const long long i = row0 + rr;
+            const size_t e = (size_t)i * J + j;
+            const real th = sh_val[(size_t)rr * NV + F], ze = sh_val[(size_t)rr * NV + F + 1];
+            const real cc = blk_C[c], nu = blk_nu[c];
+            const real lamc = sh_lamc[j], isig = sh_isig[j], rho = sh_rho[j];
+            if (A.mode == 1) {
+                const real var_ = k2 * nu;                                 // times sig2t_j
+                const real er = cc - lamc + ze + th * rho - k1 * nu;     // logT - mu_t
+                real lv, qv;
+                if constexpr (sizeof(real) == 8) { lv = fm::log(var_, logtab); qv = fm::div(er * er * isig, var_); }      // var_ = k2 nu in [1e-10 k2, 1e10 k2]
+                else { lv = r_log(var_); qv = r_div(er * er * isig, var_); }
+                llf += (double)(real(-0.5) * ((real)LOG_2PI + sh_lsig[j] + lv + qv));
+                if (post_burn && A.sum_nu) A.sum_nu[e] += (double)nu;
+                if (A.tr_nu) A.tr_nu[(size_t)trow * (size_t)A.N * J + e] = nu;     // Post.qr's vec(nu_t) (src/GibbsRtIrtCross.pl.jl:296)
+            }
+            Stream st(A.seed, A.chain, SITE_NU, (uint32_t)i + A.row_base, (uint32_t)j, sweep + 1u);
+            real nun;
+            if constexpr (sizeof(real) == 8) nun = qr_weight_q(st, fabs(cc - lamc + ze + th * rho), qr_cB, (double)(real(2) * k2 + k1 * k1) * (double)isig / (double)k2, logtab);
+            else {
+                const real den = r_div(r_sqrt(k2), r_sqrt(isig));    // sqrt(sig2t k2)
+                nun = qr_weight<real>(st, r_div(r_abs(cc - lamc + ze + th * rho), den), r_div(r_sqrt(real(2) * k2 + k1 * k1), den), logtab);
+            }
+            __hip_atomic_store(A.nu + e, nun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through: read back by the column phase behind the barrier
+        }
+        ll += llf;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
     // ---- global statistics for the next tiny step: statistic g = sum over the workgroup's subjects of va * vb (* 1/nu for the
     // sigp_mode-1 block); one wave per statistic (statistic g on wave g mod nWaves, so the work is spread over the whole workgroup),
     // lane l sums subjects l, l+64, ... in order, then a 64-lane butterfly: fixed order
@@ -1649,8 +1693,16 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                         const real inu = r_rcp(nu), ri = rr * inu;
                         bs[4] += inu; bs[5] += ri; bs[6] += rr * ri; bs[7] += nu;
                     }
+                } else if constexpr (NU_FLAT) {
+                    // CrossQr pass B: rho statistics (src/Draw.pl.jl:484-485) with the nu_{t+1} the flat phase above has just drawn (nv: read behind its barrier)
+                    const real c = cv[u];
+                    const real nun = nv[u];
+                    real ti;
+                    if constexpr (sizeof(real) == 8) ti = th * fm::rcp(nun); else ti = th * r_rcp(nun);      // nu_{t+1} is clamped to [1e-10, 1e10]
+                    bs[0] += th * ti;
+                    bs[1] += (lamc - ze - c + k1 * nun) * ti;
                 } else {
-                    // CrossQr pass B: RT log-likelihood with nu_t, then nu_{t+1} (src/Draw.pl.jl:303-320) and rho statistics (:484-485)
+                    // Cross pass B (nu == 1): RT log-likelihood and rho statistics (src/Draw.pl.jl:484-485)
                     const real c = cv[u];
                     const real nu = nv[u];
                     if (A.mode == 1) {
