@@ -43,8 +43,12 @@ struct Geom {
 
 // Small data sets -- up to this many cells, of at most this many items (every workgroup polls every workgroup's statistics row: ~5 J doubles each) -- run all
 // sweeps of an erm_run in one persistent launch of at most PERSIST_MAX_GRID workgroups (never more than one per CU) of at most PERSIST_THREADS threads
-constexpr long long PERSIST_MAX_CELLS = 1 << 17;
+#ifndef ERM_PERSIST_MAX_CELLS
+#define ERM_PERSIST_MAX_CELLS (1 << 17)
+#endif
+constexpr long long PERSIST_MAX_CELLS = ERM_PERSIST_MAX_CELLS;
 constexpr int PERSIST_MAX_ITEMS = 128;
+constexpr long long PERSIST_MAX_SUBJ = 6000;      // beyond it the subject phases of <= 64 workgroups outweigh the boundary saved (8 000 x 16: 27.6 against 26.3 us per sweep)
 constexpr int PERSIST_MAX_GRID = 64;
 
 namespace geom_detail {
@@ -190,13 +194,15 @@ inline int plan_geometry_core(const GeomIn& g, Geom& out, std::string& err)
 inline int plan_geometry(const GeomIn& g, Geom& out, std::string& err)
 {
     const bool cq = g.model == CROSSQR || g.model == CROSS;
-    const bool want = !cq && !g.no_fuse && !g.no_persist && g.N > 0 && g.J > 0 && g.N <= PERSIST_MAX_CELLS && g.N * (long long)g.J <= PERSIST_MAX_CELLS && g.J <= PERSIST_MAX_ITEMS;
+    const bool want = !cq && !g.no_fuse && !g.no_persist && g.N > 0 && g.J > 0 && g.N <= PERSIST_MAX_SUBJ && g.N * (long long)g.J <= PERSIST_MAX_CELLS && g.J <= PERSIST_MAX_ITEMS;
     const int max_grid = std::min(g.cu_count, PERSIST_MAX_GRID);
     auto fits = [&](const Geom& p) { return p.fused && p.rounds == 1 && p.grid_blocks <= max_grid && p.block_threads <= PERSIST_THREADS; };
     if (want && g.block_threads == 0 && g.grid_blocks == 0) {
         GeomIn gp = g;
         gp.block_threads = std::min(PERSIST_THREADS, max_block_threads(g.model, g.f64));
-        gp.grid_blocks = (int)std::max<long long>(1, std::min<long long>(32, (g.N + 7) / 8));
+        // measured (1 000 x 15 ... 8 000 x 16, fp64): 32 workgroups up to ~1 500 subjects (16.8 / 16.9 / 17.8 us at 250 / 500 / 1 000 x 15 against 18.4 / 18.7 / 18.8
+        // with 64), 64 beyond (2 000 x 15: 19.8 against 20.2; 4 000 x 30: 24.7 against 29.6; 6 000 x 20: 25.4 against 33.2)
+        gp.grid_blocks = g.N <= 1500 ? (int)std::max<long long>(1, std::min<long long>(32, (g.N + 7) / 8)) : std::min(64, max_grid);
         Geom p;
         std::string e2;
         if (plan_geometry_core(gp, p, e2) == 0 && fits(p)) { p.persist = true; out = p; return 0; }

@@ -69,7 +69,7 @@ static bool check(const GeomIn& g)
         REQUIRE(o.fused && !cq && !g.no_persist && !g.no_fuse, "%s: persistent where it must not be", d);
         REQUIRE(o.rounds == 1 && o.grid_blocks <= g.cu_count && o.grid_blocks <= PERSIST_MAX_GRID, "%s: persistent grid %d (rounds %d)", d, o.grid_blocks, o.rounds);
         REQUIRE(o.block_threads <= PERSIST_THREADS, "%s: persistent block of %d threads", d, o.block_threads);
-        REQUIRE(g.N * (long long)g.J <= PERSIST_MAX_CELLS && g.J <= PERSIST_MAX_ITEMS, "%s: persistent beyond its size limits", d);
+        REQUIRE(g.N * (long long)g.J <= PERSIST_MAX_CELLS && g.J <= PERSIST_MAX_ITEMS && g.N <= PERSIST_MAX_SUBJ, "%s: persistent beyond its size limits", d);
     }
     REQUIRE(o.lds_tiny <= LDS_LIMIT, "%s: tiny LDS %zu", d, o.lds_tiny);
     REQUIRE(o.n_groups == (o.grid_blocks + GROUP - 1) / GROUP && o.n_groups <= TINY_THREADS, "%s: n_groups %d", d, o.n_groups);

@@ -85,6 +85,8 @@ def test_small_data_sets_get_the_persistent_schedule(exe):
     p = plan(exe, 0, 1, 1000, 15, 3)                         # configs[0]: GibbsMlIrt 1000 x 15
     assert (p["persist"], p["block_threads"], p["grid_blocks"], p["fused"], p["rounds"]) == ("1", "512", "32", "1", "1")
     assert plan(exe, 1, 0, 1000, 15, 3)["persist"] == "1" and plan(exe, 3, 1, 2000, 15, 3)["persist"] == "1"
+    assert plan(exe, 1, 1, 4000, 30, 3)["grid_blocks"] == "64" and plan(exe, 1, 1, 4000, 30, 3)["persist"] == "1"      # 64 workgroups beyond ~1 500 subjects
+    assert plan(exe, 1, 1, 8000, 16, 3)["persist"] == "0"                       # beyond 6 000 subjects the per-sweep schedule is faster
     assert plan(exe, 1, 1, 30, 5, 3)["persist"] == "1" and int(plan(exe, 1, 1, 30, 5, 3)["grid_blocks"]) <= 4
     assert plan(exe, 1, 1, 1000, 15, 3, nopersist=1)["persist"] == "0"          # ERM_FLAG_NO_PERSIST, sharded chains
     assert plan(exe, 1, 1, 1000, 15, 3, nofuse=1)["persist"] == "0"
