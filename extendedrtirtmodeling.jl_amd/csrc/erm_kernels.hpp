@@ -74,7 +74,8 @@ __device__ __forceinline__ void persist_put(unsigned long long* row, int e, doub
 __device__ __forceinline__ double persist_get(const unsigned long long* par_rows, int nblocks, int NS, int e, uint32_t tag, unsigned int* tmo)
 {
     double t = 0.0;
-    unsigned int spins = 0;
+    // (a launch that has timed out once gives up at once from then on: its remaining sweeps must not wait another ten seconds each)
+    unsigned int spins = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? (1u << 23) : 0u;
     for (int g0 = 0; g0 < nblocks; g0 += GROUP) {
         unsigned long long lo[GROUP], hi[GROUP];
         for (;;) {
@@ -88,7 +89,7 @@ __device__ __forceinline__ double persist_get(const unsigned long long* par_rows
 #pragma unroll
             for (int u = 0; u < GROUP; ++u) ok = ok && (uint32_t)(lo[u] >> 32) == tag && (uint32_t)(hi[u] >> 32) == tag;
             if (ok) break;
-            if (++spins > (1u << 20)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > (1u << 23)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // ~10 s: another process's long erm_run may hold the CUs the last workgroups wait for
             __builtin_amdgcn_s_sleep(2);
         }
         double tg = 0.0;
