@@ -11,7 +11,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 L = pu.ge.load_package()._lib
 bad = 0
-for model, N, J in (("rtirt", 1000, 15), ("mlirt", 1000, 15), ("latentqr", 2000, 15), ("rtirt", 37, 5), ("null", 5000, 20), ("latent", 250, 100)):
+for model, N, J in (("rtirt", 1000, 15), ("mlirt", 1000, 15), ("latentqr", 2000, 15), ("rtirt", 37, 5), ("null", 5000, 20), ("latent", 250, 100), ("rtirt", 3000, 40), ("mlirt", 6000, 20)):
     Y, logT, X, init, _ = pu.make_problem(model, N, J)
     for prec in ("f64", "f32"):
         geom = {}
