@@ -236,7 +236,7 @@ def measure(pkg, ge_mod, torch, dist, args, model, N, J, F, precision, data, st,
         Y, logT, X = Y[lo:lo + n_loc], (None if logT is None else logT[lo:lo + n_loc]), (None if X is None else X[lo:lo + n_loc])
         st = dict(st, **{k: st[k][lo:lo + n_loc] for k in ("theta", "zeta") if k in st})
     eng = L.Engine(model=getattr(L, "MODEL_" + model.upper()), n_item=J, n_subj=n_loc, n_feat=0 if X is None else F, n_iter=rows, n_chain=1,
-                   n_burnin=args.warmup, cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, chain_id=0 if shard else rank, device=local_rank,
+                   n_burnin=args.warmup, cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, chain_id=0 if shard else pkg.parallel.rank_chain_id(rank), device=local_rank,
                    precision=L.PREC_F32 if precision == "f32" else L.PREC_F64,
                    trace_mode=L.TRACE_FULL if trace == "full" else L.TRACE_SUMMARY, lanes_per_row=args.lanes_per_row,
                    block_threads=args.block_threads, grid_blocks=args.grid_blocks, profile=0 if args.no_profile else 1)

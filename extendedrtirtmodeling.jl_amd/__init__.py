@@ -4,7 +4,7 @@ Export list mirrors the part of /root/reference/src/ExtendedRtIrtModeling.jl:33-
 """
 from .base import InputData, InputData4R, InputPara, OutputDic, SimConditions, setCond
 from .gibbs import (GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCross, GibbsRtIrtCrossQr, GibbsRtIrtLatent, GibbsRtIrtLatentQr, GibbsRtIrtNull,
-                    GibbsRtIrtQuantile, checkConvergence, coef, ess_rhat, getDic, simulateData,
+                    GibbsRtIrtQuantile, checkConvergence, coef, ess_rhat, getDic, getDicHost, simulateData,
                     getLogLikelihood, precis, sample, sample_b)
 from .simtools import (comparePara, getBias, getMetrics, getMetrics2, getRmse, runSimulation, setDataMlIrt, setDataRtIrt, setDataRtIrtCross,
                        setDataRtIrtLatent, setDataRtIrtNull,
@@ -16,6 +16,6 @@ __all__ = [
     "setDataMlIrt", "setDataRtIrt", "setDataRtIrtCross", "setDataRtIrtLatent", "setDataRtIrtNull", "runSimulation", "getMetrics", "getMetrics2",
     "comparePara",
     "setTrueParaMlIrt", "setTrueParaRtIrt", "setTrueParaRtIrtCross", "setTrueParaRtIrtLatent",
-    "getBias", "getRmse", "getDic", "checkConvergence", "ess_rhat", "simulateData", "getLogLikelihood", "sample_b", "sample",
+    "getBias", "getRmse", "getDic", "getDicHost", "checkConvergence", "ess_rhat", "simulateData", "getLogLikelihood", "sample_b", "sample",
     "GibbsMlIrt", "GibbsRtIrt", "GibbsRtIrtCrossQr", "GibbsRtIrtLatentQr", "GibbsRtIrtQuantile", "GibbsRtIrtNull", "GibbsRtIrtCross", "GibbsRtIrtLatent", "coef", "precis",
 ]

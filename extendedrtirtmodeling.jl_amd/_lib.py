@@ -25,7 +25,9 @@ EXPORTS = [
     "erm_set_shard", "erm_copy", "erm_rccl_unique_id", "erm_set_shard_rccl",
     "erm_farm_create", "erm_farm_destroy", "erm_farm_chains", "erm_farm_engine", "erm_farm_set_data", "erm_farm_set_state", "erm_farm_get_state",
     "erm_farm_run", "erm_farm_reset_trace", "erm_farm_get_trace", "erm_farm_get_mean", "erm_farm_post_count", "erm_farm_used_rccl", "erm_farm_get_timing",
+    "erm_get_dic", "erm_set_seed", "erm_farm_get_dic", "erm_farm_set_seed", "erm_abi_version", "erm_debug_invwishart", "erm_get_convergence",
 ]
+ABI_VERSION = 4            # ERM_ABI_VERSION of the include/ertirt.h these ctypes structs mirror
 
 
 class ErmError(RuntimeError):
@@ -43,7 +45,7 @@ class erm_config(C.Structure):
     ]
 
 
-FLAG_NO_FUSE, FLAG_NO_GRAPH, FLAG_FARM_FORCE_RCCL, FLAG_NO_PERSIST = 1, 2, 4, 8
+FLAG_NO_FUSE, FLAG_NO_GRAPH, FLAG_FARM_FORCE_RCCL, FLAG_NO_PERSIST, FLAG_TEST_PERSIST_TIMEOUT = 1, 2, 4, 8, 16
 
 
 class erm_farm_timing(C.Structure):
@@ -61,7 +63,7 @@ class erm_timing(C.Structure):
     _fields_ = [
         ("run_ms", C.c_double), ("pass_ms_total", C.c_double), ("event_overhead_ms", C.c_double), ("pass_launches", C.c_int64), ("sweeps", C.c_int64),
         ("lanes_per_row", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32), ("lds_bytes", C.c_int32),
-        ("cu_count", C.c_int32), ("persistent", C.c_int32),
+        ("cu_count", C.c_int32), ("persistent", C.c_int32), ("persist_fallbacks", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -79,6 +81,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ErmError(f"HIP extension missing: {LIB_PATH} (build it with `python -c 'import __graft_entry__ as g; g.build()'`)")
     lib = C.CDLL(LIB_PATH)
+    lib.erm_abi_version.restype = C.c_int
+    if lib.erm_abi_version() != ABI_VERSION:
+        raise ErmError(f"{LIB_PATH} has struct layout version {lib.erm_abi_version()}, this binding was written against {ABI_VERSION}: rebuild the library")
     H = C.c_void_p
     lib.erm_create.argtypes = [C.POINTER(erm_config), C.POINTER(H)]
     lib.erm_destroy.argtypes = [H]
@@ -131,6 +136,12 @@ def load():
     lib.erm_farm_post_count.restype = C.c_int64
     lib.erm_farm_used_rccl.argtypes = [H]
     lib.erm_farm_get_timing.argtypes = [H, C.POINTER(erm_farm_timing), C.c_void_p]
+    lib.erm_get_dic.argtypes = [H, C.c_void_p]
+    lib.erm_get_convergence.argtypes = [H, C.c_int, C.c_void_p]
+    lib.erm_set_seed.argtypes = [H, C.c_uint64]
+    lib.erm_farm_get_dic.argtypes = [H, C.c_void_p]
+    lib.erm_farm_set_seed.argtypes = [H, C.c_uint64]
+    lib.erm_debug_invwishart.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -220,11 +231,14 @@ class Engine:
         check(self._lib.erm_set_data(self._h, Yf.ctypes.data, None if lt is None else lt.ctypes.data,
                                      None if xx is None else xx.ctypes.data))
 
-    def simulate_data(self, seed=4321, noise=0, **truth):
-        """Generate the data set on the device from the true parameters (erm_simulate_data); returns (theta, zeta) of the truth."""
+    def simulate_data(self, seed=4321, noise=0, pull_truth=True, **truth):
+        """Generate the data set on the device from the true parameters (erm_simulate_data); returns (theta, zeta) of the truth (None with
+        pull_truth=False: they stay on the device, erm_get_truth fetches them later if wanted)."""
         arrs = {k: (None if v is None else np.asfortranarray(v, dtype=np.float64)) for k, v in truth.items()}
         st, keep = state_struct(arrs)
         check(self._lib.erm_simulate_data(self._h, C.byref(st), int(seed), int(noise)))
+        if not pull_truth:
+            return None
         th, ze = np.empty(self.cfg.n_subj), np.empty(self.cfg.n_subj)
         check(self._lib.erm_get_truth(self._h, th.ctypes.data, ze.ctypes.data))
         return th, ze
@@ -273,6 +287,17 @@ class Engine:
     def reset_trace(self):
         check(self._lib.erm_reset_trace(self._h))
 
+    def set_seed(self, seed: int):
+        """A new seed for the chain's random streams (erm_set_seed): one engine serves every replication of a simulation condition."""
+        check(self._lib.erm_set_seed(self._h, int(seed)))
+        self.cfg.seed = int(seed)
+
+    def dic(self):
+        """erm_get_dic: {Dbar, Dhat, pD, DIC} from device-resident state (the log-likelihood at Post.mean is one evaluation pass on the device)."""
+        out = np.empty(4, dtype=np.float64)
+        check(self._lib.erm_get_dic(self._h, out.ctypes.data))
+        return dict(Dbar=float(out[0]), Dhat=float(out[1]), pD=float(out[2]), DIC=float(out[3]))
+
     @property
     def rows_done(self):
         return int(self._lib.erm_rows_done(self._h))
@@ -296,6 +321,12 @@ class Engine:
         ess, rhat = np.empty(w), np.empty(w)
         check(self._lib.erm_get_diagnostics(self._h, which, ess.ctypes.data, rhat.ctypes.data))
         return ess, rhat
+
+    def convergence(self, which: int):
+        """erm_get_convergence: (columns with a defined ESS, of those ESS > 400, columns with a defined R-hat, of those R-hat < 1.1), counted on the device."""
+        c = np.zeros(4, dtype=np.int64)
+        check(self._lib.erm_get_convergence(self._h, which, c.ctypes.data))
+        return tuple(int(v) for v in c)
 
     def item_trace(self):
         w = int(self._lib.erm_item_trace_width(self._h))
@@ -400,6 +431,16 @@ class Farm:
         check(self._lib.erm_farm_get_mean(self._h, C.byref(st)))
         return bufs
 
+    def set_seed(self, seed: int):
+        check(self._lib.erm_farm_set_seed(self._h, int(seed)))
+        self.cfg.seed = int(seed)
+
+    def dic(self):
+        """erm_farm_get_dic: Dbar over the rows of all chains, Dhat at the joint Post.mean (reduced over the devices like get_mean)."""
+        out = np.empty(4, dtype=np.float64)
+        check(self._lib.erm_farm_get_dic(self._h, out.ctypes.data))
+        return dict(Dbar=float(out[0]), Dhat=float(out[1]), pD=float(out[2]), DIC=float(out[3]))
+
     def timing(self):
         """erm_farm_get_timing: wall-clock of the last run / gather, per-chain device time, ranks of the library's RCCL communicator."""
         t = erm_farm_timing()
@@ -448,3 +489,11 @@ def sample_gig(p, a, b, n, *, seed=1234, site=15, sweep=1, device=0):
     out = np.empty(int(n), dtype=np.float64)
     check(load().erm_sample_gig(device, seed, site, sweep, int(n), float(p), float(a), float(b), out.ctypes.data))
     return out
+
+
+def debug_invwishart(nu, psi, n, *, seed=1234, sweep=1, device=0):
+    """n draws of the structural step's 2 x 2 InverseWishart(nu, Psi) (erm_debug_invwishart): an (n, 2, 2) array."""
+    psi = np.ascontiguousarray(np.asarray(psi, dtype=np.float64).reshape(2, 2).T).reshape(4)      # vec(Psi), column-major
+    out = np.empty((int(n), 4), dtype=np.float64)
+    check(load().erm_debug_invwishart(device, int(seed), int(sweep), int(n), float(nu), psi.ctypes.data, out.ctypes.data))
+    return out.reshape(int(n), 2, 2).transpose(0, 2, 1)

@@ -190,14 +190,15 @@ inline int plan_geometry_core(const GeomIn& g, Geom& out, std::string& err)
 }
 
 // The plan the engine uses: the persistent schedule for small data sets of the single-pass models (its own geometry unless the caller gave one),
-// otherwise the per-sweep plan.
+// otherwise the per-sweep plan.  `no_persist` (ERM_FLAG_NO_PERSIST, sharded chains, the fallback after a persistent launch timed out) changes the
+// SCHEDULE only: the geometry stays the persistent plan's, so the statistics are summed in the same association and the chain is the same bit for bit.
 inline int plan_geometry(const GeomIn& g, Geom& out, std::string& err)
 {
     const bool cq = g.model == CROSSQR || g.model == CROSS;
-    const bool want = !cq && !g.no_fuse && !g.no_persist && g.N > 0 && g.J > 0 && g.N <= PERSIST_MAX_SUBJ && g.N * (long long)g.J <= PERSIST_MAX_CELLS && g.J <= PERSIST_MAX_ITEMS;
+    const bool shape = !cq && !g.no_fuse && g.N > 0 && g.J > 0 && g.N <= PERSIST_MAX_SUBJ && g.N * (long long)g.J <= PERSIST_MAX_CELLS && g.J <= PERSIST_MAX_ITEMS;
     const int max_grid = std::min(g.cu_count, PERSIST_MAX_GRID);
     auto fits = [&](const Geom& p) { return p.fused && p.rounds == 1 && p.grid_blocks <= max_grid && p.block_threads <= PERSIST_THREADS; };
-    if (want && g.block_threads == 0 && g.grid_blocks == 0) {
+    if (shape && g.block_threads == 0 && g.grid_blocks == 0) {
         GeomIn gp = g;
         gp.block_threads = std::min(PERSIST_THREADS, max_block_threads(g.model, g.f64));
         // measured (1 000 x 15 ... 8 000 x 16, fp64): 32 workgroups up to ~1 500 subjects (16.8 / 16.9 / 17.8 us at 250 / 500 / 1 000 x 15 against 18.4 / 18.7 / 18.8
@@ -205,10 +206,10 @@ inline int plan_geometry(const GeomIn& g, Geom& out, std::string& err)
         gp.grid_blocks = g.N <= 1500 ? (int)std::max<long long>(1, std::min<long long>(32, (g.N + 7) / 8)) : std::min(64, max_grid);
         Geom p;
         std::string e2;
-        if (plan_geometry_core(gp, p, e2) == 0 && fits(p)) { p.persist = true; out = p; return 0; }
+        if (plan_geometry_core(gp, p, e2) == 0 && fits(p)) { p.persist = !g.no_persist; out = p; return 0; }
     }
     if (int rc = plan_geometry_core(g, out, err)) return rc;
-    out.persist = want && fits(out);
+    out.persist = shape && !g.no_persist && fits(out);
     return 0;
 }
 

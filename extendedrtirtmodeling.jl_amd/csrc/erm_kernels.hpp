@@ -25,6 +25,9 @@ struct Ctl {
     uint32_t row;         // trace row of that sweep within the current sample! call
     uint32_t burn_rows;   // rows < burn_rows are burn-in (not accumulated into Post.mean)
     uint32_t err;         // sticky non-finite flag
+    uint32_t first;       // 1 until the first sweep of the current erm_run has been drawn (that sweep writes trace row `row` itself instead of row + 1, and no
+                          // log-likelihood of a preceding pass): device-side, so that every sweep of a run is the same launch and whole runs replay from graphs
+    uint32_t pad_;
     unsigned long long dbg_attempts, dbg_trips, dbg_cells;   // -DERM_DIAG_BUILD with ERM_PASS_STOP=9: PG attempts, wave trips, cells
 };
 
@@ -61,8 +64,8 @@ template <typename real> struct PassArgs {
 // packets {tag : 32 | half : 32}, each ONE 8-byte agent-scope store (atomic by size), and the readers poll the packets themselves: one store trip
 // plus one load trip, no counter, no fence, no ordering between packets needed.  xbuf[parity][workgroup][2 * NS]; a row written after sweep k goes
 // to parity k & 1 with tag tag0 + k + 1.  No workgroup can overwrite a row another still waits for: writing the row of sweep k + 2 takes every
-// workgroup's row of sweep k + 1, which a workgroup writes only after it has read all rows of sweep k.  The spin is bounded: on timeout the
-// launch sets *tmo, runs on with garbage, and erm_run reports it.
+// workgroup's row of sweep k + 1, which a workgroup writes only after it has read all rows of sweep k.  The wait is bounded by the wall clock: on
+// time-out the launch sets *tmo, every workgroup leaves the sweep loop at its next head, and erm_run replays the call on the per-sweep schedule.
 __device__ __forceinline__ void persist_put(unsigned long long* row, int e, double v, uint32_t tag)
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
@@ -70,12 +73,15 @@ __device__ __forceinline__ void persist_put(unsigned long long* row, int e, doub
     __hip_atomic_store(row + 2 * e + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // entry e of the sum over all workgroups' rows, in the association of the per-sweep path (group sums of GROUP rows in workgroup order, then the
-// groups in order: the epilogue's group reduction followed by reduce_rows), so that the chain does not depend on the schedule
+// groups in order: the epilogue's group reduction followed by reduce_rows), so that the chain does not depend on the schedule.
+// tmo[0]: the launch's time-out flag, tmo[1]: the bound of one wait in ticks of the 100 MHz wall clock (1 s; set by the host with every erm_run),
+// tmo[2]: fault injection for the tests (ERM_FLAG_TEST_PERSIST_TIMEOUT).  A wait that fails takes the clock once and from then on compares; a launch that
+// has timed out anywhere gives up at once everywhere (every workgroup leaves the sweep loop at its next head: pass_kernel), and erm_run restores the state
+// it saved and replays the call on the per-sweep schedule.
 __device__ __forceinline__ double persist_get(const unsigned long long* par_rows, int nblocks, int NS, int e, uint32_t tag, unsigned int* tmo)
 {
     double t = 0.0;
-    // (a launch that has timed out once gives up at once from then on: its remaining sweeps must not wait another ten seconds each)
-    unsigned int spins = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? (1u << 23) : 0u;
+    unsigned long long t_end = 0ull;
     for (int g0 = 0; g0 < nblocks; g0 += GROUP) {
         unsigned long long lo[GROUP], hi[GROUP];
         for (;;) {
@@ -89,7 +95,10 @@ __device__ __forceinline__ double persist_get(const unsigned long long* par_rows
 #pragma unroll
             for (int u = 0; u < GROUP; ++u) ok = ok && (uint32_t)(lo[u] >> 32) == tag && (uint32_t)(hi[u] >> 32) == tag;
             if (ok) break;
-            if (++spins > (1u << 23)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // ~10 s: another process's long erm_run may hold the CUs the last workgroups wait for
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            const unsigned long long now = wall_clock64();
+            if (t_end == 0ull) t_end = now + (unsigned long long)__hip_atomic_load(tmo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (now > t_end) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             __builtin_amdgcn_s_sleep(2);
         }
         double tg = 0.0;
@@ -171,7 +180,6 @@ struct TinyArgs {
     double* tr_ll;        // [rows]
     long long N; int J; int nFeat; int nb0, nb1;
     int mode;             // 0 = draw sweep (advance ctl), 1 = final (only reduce the last pass's log-likelihood)
-    int first;            // 1 if no full pass precedes this step in the current sample! call
     int intercept, onepl, cov2one, sigp_mode;
     uint32_t chain; uint64_t seed; double k1, k2;
     int nq;               // number of small qr entries recorded per sweep
@@ -187,6 +195,28 @@ __device__ inline void d_cov2one(double* S)   // src/Draw.pl.jl:507-511
     const double d2 = q_rcp(q_sqrt(S[3]));
     S[3] *= d2 * d2; S[1] *= d2; S[2] *= d2;
     S[0] = 1.0; S[3] = 1.0;
+}
+
+// 2 x 2 InverseWishart(df, Psi) of drawSubjCovariance (src/Draw.pl.jl:499-515): W ~ Wishart(df, Psi^-1) by its Bartlett factor (L = chol(Psi^-1),
+// A = [c1 0; n21 c2] with c1^2 ~ chi2(df), n21 ~ N(0,1), c2^2 ~ chi2(df - 1): W = L A A' L'), then W^-1.  The three variates are drawn apart from the
+// matrix arithmetic (in the sweep kernel by another thread, while the statistics they do not depend on are still being reduced); the unit test
+// (erm_debug_invwishart) runs the two functions back to back.
+__device__ __forceinline__ void bartlett2_variates(Stream& ss, double df, double* v3)
+{
+    v3[0] = q_sqrt(chisq(ss, df));
+    v3[1] = normal<double>(ss);
+    v3[2] = q_sqrt(chisq(ss, df - 1.0));
+}
+__device__ __forceinline__ void invwishart2(const double* Psi, const double* v3, double* S)
+{
+    const double ipdet = q_rcp(Psi[0] * Psi[3] - Psi[1] * Psi[2]);
+    const double Pi[4] = { Psi[3] * ipdet, -Psi[1] * ipdet, -Psi[2] * ipdet, Psi[0] * ipdet };
+    const double l00 = q_sqrt(Pi[0]), l10 = q_div(Pi[1], l00), l11 = q_sqrt(Pi[3] - l10 * l10);
+    const double c1 = v3[0], n21 = v3[1], c2 = v3[2];
+    const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
+    const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
+    const double idet = q_rcp(Wm[0] * Wm[3] - Wm[1] * Wm[2]);
+    S[0] = Wm[3] * idet; S[1] = -Wm[1] * idet; S[2] = -Wm[2] * idet; S[3] = Wm[0] * idet;
 }
 
 // lower Cholesky factor of the n x n matrix V (column-major, leading dimension n) into L: one column per step, rows in parallel
@@ -282,10 +312,7 @@ __device__ __forceinline__ void tiny_items(const TinyArgs& T, double* par, const
     if (tid == (nthreads > 64 ? 64 : 0) && STEP == 0 && MODEL != MLIRT) {
         Stream ss(T.seed, T.chain, SITE_SIGP, 0u, 0u, sweep);
         if (fam_rt(MODEL)) {
-            const double df = Nd + 3.0;
-            spd[0] = q_sqrt(chisq(ss, df));
-            spd[1] = normal<double>(ss);
-            spd[2] = q_sqrt(chisq(ss, df - 1.0));
+            bartlett2_variates(ss, Nd + 3.0, spd);
         } else {
             spd[0] = gamma_mt(ss, 1e-3 + (MODEL == LATENTQR ? Nd * 3.0 / 2.0 : Nd / 2.0));
         }
@@ -564,14 +591,7 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
             const double ee01 = tz - bx[0 + 2 * 1] - bx[1 + 2 * 0] + bAb[0 + 2 * 1];
             const double ee11 = zz - 2.0 * bx[3] + bAb[3];
             const double Psi[4] = { ee00 + 1.0, ee01, ee01, ee11 + 1.0 };
-            const double ipdet = q_rcp(Psi[0] * Psi[3] - Psi[1] * Psi[2]);
-            const double Pi[4] = { Psi[3] * ipdet, -Psi[1] * ipdet, -Psi[2] * ipdet, Psi[0] * ipdet };
-            const double l00 = q_sqrt(Pi[0]), l10 = q_div(Pi[1], l00), l11 = q_sqrt(Pi[3] - l10 * l10);
-            const double c1 = spd[0], n21 = spd[1], c2 = spd[2];
-            const double z00 = l00 * c1, z10 = l10 * c1 + l11 * n21, z11 = l11 * c2;
-            const double Wm[4] = { z00 * z00, z10 * z00, z00 * z10, z10 * z10 + z11 * z11 };
-            const double idet = q_rcp(Wm[0] * Wm[3] - Wm[1] * Wm[2]);
-            S[0] = Wm[3] * idet; S[1] = -Wm[1] * idet; S[2] = -Wm[2] * idet; S[3] = Wm[0] * idet;
+            invwishart2(Psi, spd, S);
         } else if (MODEL == LATENT) {
             // drawSubjCovarianceLatent src/Draw.pl.jl:563-579 : InverseGamma(da + N/2, db + sum((zeta - x beta)^2)/2), x = [1 X theta]
             const double* xt = G0; const double tt = G0[p]; const double* xz = G0 + p + 1;
@@ -658,7 +678,7 @@ __device__ __forceinline__ void tiny_publish(const TinyArgs& T, const double* pa
         if (!(fabs(par[e]) < 1e300)) atomicCAS(&T.ctl_err->err, 0u, 1u + (uint32_t)e);   // a non-finite entry of the parameter block
         par_out[e] = par[e];
     }
-    if (tid == 0 && STEP == 0) { ctl_out->sweep = sweep; ctl_out->row = row; ctl_out->burn_rows = burn_rows; }
+    if (tid == 0 && STEP == 0) { ctl_out->sweep = sweep; ctl_out->row = row; ctl_out->burn_rows = burn_rows; ctl_out->first = 0u; }
 }
 
 
@@ -761,6 +781,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     }
     uint32_t c_sweep = A.ctl->sweep, c_row = A.ctl->row;        // the chain's counters: read once, carried in registers through a persistent launch
     const uint32_t c_burn = A.ctl->burn_rows;
+    [[maybe_unused]] const uint32_t c_first = A.ctl->first;     // no sweep of this erm_run has been drawn yet
     asm volatile("" ::: "memory");                  // the loads above stay above the table arithmetic below
     // fp64 engine: the 2 KB table of fm::log (filled here; the first barrier below -- the head's, or the staging barrier -- publishes it)
     [[maybe_unused]] const double2* logtab = nullptr;
@@ -844,7 +865,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     const TinyArgs& T = LAUNDER ? *reinterpret_cast<const TinyArgs*>((const char*)kap + ((sizeof(PassArgs<real>) + 7) & ~(size_t)7)) : T_;
     // this sweep's halves of the double buffers (a persistent launch alternates them as consecutive launches do; A and T themselves stay untouched --
     // as modified private copies every field of the two argument structs lived in a scalar register for the whole loop: 250 more SGPR spills)
-    double* k_par_out = T.par_out; Ctl* k_ctl_out = T.ctl_out; double* k_gslab_out = A.gslab; int k_first = T.first;
+    double* k_par_out = T.par_out; Ctl* k_ctl_out = T.ctl_out; double* k_gslab_out = A.gslab; int k_first = (int)c_first;
     if constexpr (PERSIST) {
         const bool odd = ((A.cur0 + ks) & 1u) != 0u;
         k_par_out = odd ? A.parB[0] : A.parB[1];
@@ -872,8 +893,14 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
             // the statistics arrive as packets
             const unsigned long long* rows = A.xbuf + (size_t)((ks - 1u) & 1u) * gridDim.x * 2 * NS0;
             for (int e = tid; e < NS0; e += nthr) st0[e] = persist_get(rows, (int)gridDim.x, NS0, e, A.tag0 + ks, A.tmo);
+            // the launch's time-out flag as this workgroup sees it now (the upper half of the row-group counter's slot is free): published by the barrier below
+            if (tid == 0) reinterpret_cast<unsigned int*>(sh_struct + 7)[1] = __hip_atomic_load(A.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
+        if constexpr (PERSIST) {
+            // a launch that has timed out is abandoned by every workgroup (uniformly: all threads read the same LDS word); erm_run restores the saved state
+            if (ks > 0 && reinterpret_cast<const unsigned int*>(sh_struct + 7)[1] != 0u) __builtin_amdgcn_endpgm();
+        }
         stamp(1);
         const uint32_t prev_row = c_row;
         sweep = c_sweep + 1u;
@@ -1756,11 +1783,14 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     __syncthreads();
     const int NS = NSTAT * J + NG;
     double* out = A.slab + (size_t)blockIdx.x * NS;
+    // (tests, ERM_FLAG_TEST_PERSIST_TIMEOUT: workgroup 1 loses its first statistics row, so that the launch times out and erm_run falls back)
+    [[maybe_unused]] bool lose_row = false;
+    if constexpr (PERSIST) lose_row = ks == 0u && blockIdx.x == 1u && A.tmo[2] != 0u;
     for (int e = threadIdx.x; e < NS; e += blockDim.x) {
         double t = 0.0;
         if (e < NSTAT * J) { for (int w = 0; w < nWaves; ++w) t += sh_acc[(size_t)w * NSTAT * J + e]; }
         else { const int gi = e - NSTAT * J; for (int w = 0; w < nWaves; ++w) t += sh_gacc[(size_t)w * NG + gi]; }
-        if (PERSIST && ks + 1u < n_loop) persist_put(A.xbuf + ((size_t)(ks & 1u) * gridDim.x + blockIdx.x) * 2 * NS, e, t, A.tag0 + ks + 1u);
+        if (PERSIST && ks + 1u < n_loop) { if (!lose_row) persist_put(A.xbuf + ((size_t)(ks & 1u) * gridDim.x + blockIdx.x) * 2 * NS, e, t, A.tag0 + ks + 1u); }
         else __hip_atomic_store(out + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through (sc1) store: no release fence needed
     }
     if (PERSIST && ks + 1u < n_loop) {
@@ -1888,11 +1918,12 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     __syncthreads();
 
     const uint32_t prev_row = T.ctl->row;
+    const bool first = T.ctl->first != 0u;                  // no sweep of this erm_run precedes this step
     const uint32_t sweep = T.ctl->sweep + ((T.mode == 0 && STEP == 0) ? 1u : 0u);   // the sweep being drawn
-    const uint32_t row = (T.mode == 0 && STEP == 0 && !T.first) ? prev_row + 1u : prev_row;
+    const uint32_t row = (T.mode == 0 && STEP == 0 && !first) ? prev_row + 1u : prev_row;
 
     // ---- log-likelihood of the sweep the last full pass completed
-    if (STEP == 0 && tid == 0 && !T.first && T.tr_ll) {
+    if (STEP == 0 && tid == 0 && !first && T.tr_ll) {
         double llv = st0[NS0 - 1];
         if (fam_cq(MODEL)) llv += st1[NS1 - 1];
         T.tr_ll[prev_row] = llv;
@@ -2153,6 +2184,175 @@ __global__ void center_kernel(real* C, long long N, int J, const double* mean, d
         }
         part[(size_t)blockIdx.x * J + j] = sq;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// erm_run's bookkeeping in two small launches.  As separate stream operations (two host -> device copies of the counters, a fill of the tickets, three
+// device -> host copies at the end) they were ~45 us of device time per erm_run -- more than two microseconds per sweep of a 20-sweep call.
+//   run_begin_kernel : both copies of the chain's counters, the group tickets zeroed, the persistent launch's wait bound and test hook;
+//   run_end_kernel   : the counters of both buffers and the time-out word into PINNED HOST memory (visible to the host once the stream has drained).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) run_begin_kernel(Ctl* c0, Ctl* c1, Ctl v, unsigned int* gcnt, int n_gcnt, unsigned int tmo_ticks, unsigned int tmo_fault)
+{
+    const int t = (int)threadIdx.x;
+    if (t == 0) { *c0 = v; *c1 = v; }
+    for (int k = t; k < n_gcnt; k += (int)blockDim.x) gcnt[k] = (k == n_gcnt - 3) ? tmo_ticks : ((k == n_gcnt - 2) ? tmo_fault : 0u);      // [tickets | tmo flag, ticks, fault, pad]
+}
+__global__ void __launch_bounds__(64) run_end_kernel(const Ctl* c0, const Ctl* c1, const unsigned int* tmo, Ctl* host_out, unsigned int* host_tmo)
+{
+    if (threadIdx.x == 0) { host_out[0] = *c0; host_out[1] = *c1; *host_tmo = *tmo; }
+}
+// up to 10 device buffers copied by ONE launch: the state a persistent erm_run saves before it starts (and restores if the launch times out)
+struct CopySegs { const void* src[10]; void* dst[10]; unsigned long long bytes[10]; int n; };
+__global__ void __launch_bounds__(256) copy_segments_kernel(CopySegs S)
+{
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gn = (size_t)gridDim.x * blockDim.x;
+    for (int k = 0; k < S.n; ++k) {
+        const size_t nb = (size_t)S.bytes[k], nw = nb / 16;                       // hipMalloc'd buffers: 256-byte aligned
+        const uint4* s = reinterpret_cast<const uint4*>(S.src[k]);
+        uint4* d = reinterpret_cast<uint4*>(S.dst[k]);
+        for (size_t i = gt; i < nw; i += gn) d[i] = s[i];
+        for (size_t i = nw * 16 + gt; i < nb; i += gn) reinterpret_cast<unsigned char*>(S.dst[k])[i] = reinterpret_cast<const unsigned char*>(S.src[k])[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DIC on the device.  getDic (src/GibbsRtIrt.pl.jl:432-472, src/GibbsRtIrtCross.pl.jl:330-353, src/GibbsRtIrtLatent.pl.jl:342-365):
+//   Dhat = -2 logLik(Post.mean), Dbar = -2 mean(Post.logLike) over all iterations, pD = Dbar - Dhat, DIC = Dbar + pD.
+// Post.mean never leaves the device: the post-burn-in SUMS of the subject-level draws are resident (sum_theta / sum_zeta / sum_nu), the item-level
+// ones are summed from the resident item trace (item_sum_kernel, row order), and loglik_kernel evaluates the model's log-likelihood
+//   getLogLikelihoodMlIrt / RtIrt / RtIrtNull (src/GibbsRtIrt.pl.jl:195-204, 262-272, 351-362), ...Cross / CrossQr (src/GibbsRtIrtCross.pl.jl:158-170, 240-258),
+//   ...Latent / LatentQr (src/GibbsRtIrtLatent.pl.jl:151-162, 243-264)
+// at sums * inv over the resident data set.  Plain fp64 with libm's log1p / exp / log (this runs once per sample!, not per sweep); every thread adds its
+// terms in a fixed order, a workgroup's threads are summed by a fixed tree, the host adds the workgroups' partial sums in order: reproducible bit for bit.
+// `sum` layout (the chain farm's summary vector): [item-level trace columns: a b lambda sig2t | small part of qr][theta N][zeta N, response-time models][nu N or N*J].
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) item_sum_kernel(const double* tr_item, long long wi, long long row0, long long row1, double* out)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= wi) return;
+    double t = 0.0;
+    for (long long r = row0; r < row1; ++r) t += tr_item[r * wi + k];
+    out[k] += t;
+}
+// sum of the first n entries of the log-likelihood trace: thread t adds entries t, t + 256, ... in order, then a fixed tree
+__global__ void __launch_bounds__(256) ll_trace_sum_kernel(const double* tr_ll, long long n, double* out)
+{
+    __shared__ double sh[256];
+    double t = 0.0;
+    for (long long r = threadIdx.x; r < n; r += 256) t += tr_ll[r];
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+struct LogLikArgs {
+    const uint8_t* Y; const void* C; const void* X;      // resident data set: Y u8 [N][J], centred logT and X in the engine's cell type, row-major
+    const double* cm;                                     // column means of logT [J]
+    const double* sum; double inv;                        // Post.mean = sum * inv
+    long long N; int J, F, model;                         // F = covariate columns the kernels see
+    long long off_theta, off_zeta, off_nu;                // offsets into `sum` (off_zeta / off_nu < 0: absent)
+    double k1, k2;
+    long long rows_per_block;
+    double* part;                                         // [gridDim.x]
+};
+__device__ inline double ll_log1pexp(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+template <typename real>
+__global__ void __launch_bounds__(256) loglik_kernel(LogLikArgs D)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* sa = reinterpret_cast<double*>(smem);        // a b lambda sig2t rho [5][J] | Sigp [4] | beta [2 PMAX]
+    const int J = D.J, F = D.F, p = F + 1, M = D.model, tid = (int)threadIdx.x;
+    double* sb = sa + J, *sl = sa + 2 * J, *sg = sa + 3 * J, *sr = sa + 4 * J, *sS = sa + 5 * J, *sbeta = sS + 4;
+    __shared__ double red[256];
+    for (int e = tid; e < 4 * J; e += 256) sa[e] = D.sum[e] * D.inv;
+    const double* q = D.sum + 4 * J;                      // the small part of qr (tiny_publish's order)
+    for (int j = tid; j < J; j += 256) sr[j] = fam_cq(M) ? q[j] * D.inv : 0.0;
+    if (tid < 4) sS[tid] = (M == MLIRT) ? (tid == 0 || tid == 3 ? 1.0 : 0.0) : q[(fam_cq(M) ? J : (fam_rt(M) ? 2 * p : p + 1)) + tid] * D.inv;
+    if (tid < 2 * PMAX) {
+        double v = 0.0;
+        if (M == MLIRT) { if (tid < p) v = q[tid] * D.inv; }
+        else if (M == RTIRT) { if (tid < p) v = q[tid] * D.inv; else if (tid >= PMAX && tid < PMAX + p) v = q[p + tid - PMAX] * D.inv; }      // [theta column | zeta column at PMAX]
+        else if (fam_lq(M)) { if (tid < p + 1) v = q[tid] * D.inv; }
+        sbeta[tid] = v;
+    }
+    __syncthreads();
+    const real* C = reinterpret_cast<const real*>(D.C);
+    const real* X = reinterpret_cast<const real*>(D.X);
+    const long long r0 = (long long)blockIdx.x * D.rows_per_block, r1 = (r0 + D.rows_per_block < D.N) ? r0 + D.rows_per_block : D.N;
+    const long long ncell = (r1 > r0 ? r1 - r0 : 0) * J;
+    double ll = 0.0;
+    const bool qw = M == CROSSQR;                         // per-cell quantile weights
+    for (long long c = tid; c < ncell; c += 256) {
+        const long long i = r0 + c / J;
+        const int j = (int)(c % J);
+        const size_t e = (size_t)i * J + j;
+        const double th = D.sum[D.off_theta + i] * D.inv;
+        const double eta = sa[j] * (th - sb[j]);
+        ll += (D.Y[e] ? eta : 0.0) - ll_log1pexp(eta);
+        if (M != MLIRT) {
+            const double ze = D.sum[D.off_zeta + i] * D.inv;
+            const double lt = (double)C[e] + D.cm[j];
+            double mu = sl[j] - ze, var = sg[j];
+            if (fam_cq(M)) {
+                const double nu = qw ? D.sum[D.off_nu + (long long)e] * D.inv : 1.0;
+                mu += -th * sr[j] + D.k1 * nu;
+                var *= D.k2 * nu;
+            }
+            const double er = lt - mu;
+            ll += -0.5 * LOG_2PI - 0.5 * log(var) - 0.5 * er * er / var;
+        }
+    }
+    const double det = sS[0] * sS[3] - sS[1] * sS[2];
+    for (long long i = r0 + tid; i < r1; i += 256) {
+        const double th = D.sum[D.off_theta + i] * D.inv;
+        double xb0 = 0.0, xb1 = 0.0;
+        if (M == MLIRT || M == RTIRT || fam_lq(M)) {
+            xb0 = sbeta[0]; xb1 = sbeta[PMAX];
+            for (int f = 0; f < F; ++f) { const double x = (double)X[(size_t)i * F + f]; xb0 += x * sbeta[1 + f]; xb1 += x * sbeta[PMAX + 1 + f]; }
+        }
+        if (M == MLIRT) { const double e0 = th - xb0; ll += -0.5 * LOG_2PI - 0.5 * e0 * e0; continue; }
+        const double ze = D.sum[D.off_zeta + i] * D.inv;
+        if (fam_lq(M)) {
+            const double nu = (M == LATENTQR) ? D.sum[D.off_nu + i] * D.inv : 1.0;
+            const double mu = xb0 + th * sbeta[p] + D.k1 * nu, var = sS[3] * D.k2 * nu, er = ze - mu;
+            ll += -0.5 * LOG_2PI - 0.5 * log(var) - 0.5 * er * er / var;
+        } else {
+            const double e0 = th - (M == RTIRT ? xb0 : 0.0), e1 = ze - (M == RTIRT ? xb1 : 0.0);
+            const double quad = (sS[3] * e0 * e0 - (sS[1] + sS[2]) * e0 * e1 + sS[0] * e1 * e1) / det;
+            ll += -LOG_2PI - 0.5 * log(det) - 0.5 * quad;
+        }
+    }
+    red[tid] = ll;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
+    if (tid == 0) D.part[blockIdx.x] = red[0];
+}
+
+// checkConvergence's counts (src/SimTools.jl:427-437) from the device arrays of ess / rhat: c[0] columns with a defined ESS, c[1] of them with ESS > ess_min,
+// c[2] columns with a defined R-hat, c[3] of them with R-hat < rhat_max (integer atomics: order-independent)
+__global__ void __launch_bounds__(256) diag_count_kernel(const double* ess, const double* rhat, long long n, double ess_min, double rhat_max, unsigned long long* c)
+{
+    unsigned long long t[4] = {0ull, 0ull, 0ull, 0ull};
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        const double e = ess[k], r = rhat[k];
+        if (e == e) { ++t[0]; if (e > ess_min) ++t[1]; }
+        if (r == r) { ++t[2]; if (r < rhat_max) ++t[3]; }
+    }
+    for (int q = 0; q < 4; ++q) if (t[q]) atomicAdd(c + q, t[q]);
+}
+
+// n draws of the structural step's 2 x 2 inverse Wishart (erm_debug_invwishart): stream (seed, SIGP, i = k, sweep)
+__global__ void __launch_bounds__(256) invwishart_batch_kernel(uint64_t seed, uint32_t sweep, long long n, double df, double p0, double p1, double p2, double p3, double* out)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Stream ss(seed, 0u, SITE_SIGP, (uint32_t)k, 0u, sweep);
+    double v3[3], S[4];
+    const double Psi[4] = { p0, p1, p2, p3 };
+    bartlett2_variates(ss, df, v3);
+    invwishart2(Psi, v3, S);
+    for (int e = 0; e < 4; ++e) out[4 * k + e] = S[e];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -114,6 +114,12 @@ struct EngineBase {
     virtual int get_item_trace(double*) = 0;
     virtual int get_mean(erm_state*) = 0;
     virtual int get_diagnostics(int, double*, double*) = 0;
+    virtual int get_convergence(int, int64_t*) = 0;
+    virtual int get_dic(double*) = 0;
+    virtual int set_seed(uint64_t) = 0;
+    // DIC pieces for the chain farm: the log-likelihood at sum * inv (sum: a device vector in the summary layout) and the sum of the recorded logLike rows
+    virtual int loglik_at(const double* dsum, double inv, double* ll) = 0;
+    virtual int ll_trace_sum(double* out) = 0;
     virtual int simulate_data(const erm_state*, uint64_t, int) = 0;
     virtual int get_data(uint8_t*, double*, double*) = 0;
     virtual int get_truth(double*, double*) = 0;
@@ -178,6 +184,9 @@ template <typename real> struct Engine : EngineBase {
     DevBuf dParB[2], dCtlB[2], dGslab0B[2];
     DevBuf dDbgTs;                                   // ERM_TIMELINE diagnostics
     DevBuf dXbuf;                                    // persistent launches: packet rows of the statistics exchange
+    DevBuf dSnap;                                    // persistent launches: the state saved before an erm_run (restored if the launch times out: run())
+    bool snap_stats_valid = false;
+    int persist_fault_countdown = 0;                 // ERM_FLAG_TEST_PERSIST_TIMEOUT: the engine's SECOND persistent erm_run loses a statistics row (the first leaves rows and sums for the restore to keep)
     uint32_t xtag = 0;                               // last packet tag handed out (tags only grow; the buffer is cleared before they wrap)
     int cur = 0;
     int n_groups = 1;
@@ -194,9 +203,7 @@ template <typename real> struct Engine : EngineBase {
     DevBuf dSumTheta, dSumZeta, dSumNu, dTrTheta, dTrZeta, dTrNu, dTrItem, dTrLl;
 
     ~Engine() override {
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        if (graph_tail) (void)hipGraphExecDestroy(graph_tail);
-        if (graph_mid) (void)hipGraphExecDestroy(graph_mid);
+        drop_graphs();
         if (comm) (void)g_rccl.CommDestroy(comm);
         for (auto e : pass_ev) (void)hipEventDestroy(e);
         if (host_ctl) (void)hipHostFree(host_ctl);
@@ -243,6 +250,11 @@ template <typename real> struct Engine : EngineBase {
             return fail(ERM_ERR_ARG, "qRt must be between 0 and 1");   // @assert at src/Draw.pl.jl:476
         if (cfg.n_iter < 0 || cfg.n_chain < 1 || cfg.n_burnin < 0) return fail(ERM_ERR_ARG, "bad n_iter / n_chain / n_burnin");
         if (cfg.sigp_mode != 0 && cfg.sigp_mode != 1) return fail(ERM_ERR_ARG, "sigp_mode must be 0 or 1");
+        if (cfg.chain_id < 0 || cfg.chain_id > 255) return fail(ERM_ERR_ARG, "chain_id must be in [0, 255] (the random streams carry eight bits of it: chain 256 would replay chain 0)");
+        if (cfg.flags & ~(int32_t)ERM_FLAG_ALL) return fail(ERM_ERR_ARG, "unknown bits in erm_config.flags (built against another version of ertirt.h? erm_abi_version() = " + std::to_string(ERM_ABI_VERSION) + ")");
+        if (!(cfg.nu_trace_max_gb >= 0.0) || !std::isfinite(cfg.nu_trace_max_gb)) return fail(ERM_ERR_ARG, "nu_trace_max_gb must be finite and non-negative (0 = the default)");
+        if (cfg.precision != ERM_PREC_F32 && cfg.precision != ERM_PREC_F64) return fail(ERM_ERR_ARG, "unknown precision");
+        if (cfg.trace_mode != ERM_TRACE_SUMMARY && cfg.trace_mode != ERM_TRACE_FULL) return fail(ERM_ERR_ARG, "unknown trace_mode");
         HIPCHK(hipSetDevice(cfg.device));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
@@ -250,7 +262,8 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&ev0));
         HIPCHK(hipEventCreate(&ev1));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 4 * sizeof(Ctl), hipHostMallocDefault));      // [0] upload, [1], [2] read-back of the two device copies, [3] a persistent launch's time-out word
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 4 * sizeof(Ctl), hipHostMallocDefault));      // [1], [2]: the two device copies of the counters, [3]: a persistent launch's time-out word -- written by run_end_kernel
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_ctl_dev), host_ctl, 0));
 
         // ---- geometry (pure host function, CPU-tested: erm_geometry.hpp)
         {
@@ -288,11 +301,12 @@ template <typename real> struct Engine : EngineBase {
         rc |= dSlab0.alloc((size_t)grid_blocks * ns[0] * sizeof(double));
         // (at least GROUP rows, zero-filled: the fused head requests its first GROUP group rows unconditionally and masks those beyond n_groups)
         for (int k = 0; k < 2; ++k) rc |= dGslab0B[k].alloc((size_t)std::max(n_groups, GROUP) * ns[0] * sizeof(double));
-        rc |= dGcnt.alloc(((size_t)2 * n_groups + 2) * sizeof(unsigned int));       // group tickets | timeout word of a persistent launch
+        rc |= dGcnt.alloc(((size_t)2 * n_groups + 4) * sizeof(unsigned int));       // group tickets | a persistent launch's time-out flag, wait bound (ticks), test hook, pad
         if (persist) {      // packet rows of the persistent launch's statistics exchange: [parity][workgroup][2 * ns] 64-bit packets, tags start at 1
             rc |= dXbuf.alloc((size_t)2 * grid_blocks * 2 * ns[0] * sizeof(unsigned long long));
             if (!rc) HIPCHK(hipMemset(dXbuf.p, 0, dXbuf.bytes));
         }
+        if (persist) rc |= dSnap.alloc(snap_bytes());
         if (m_cq()) { rc |= dSlab1.alloc((size_t)grid_blocks * ns[1] * sizeof(double)); rc |= dGslab1.alloc((size_t)std::max(n_groups, GROUP) * ns[1] * sizeof(double)); }      // >= GROUP rows: see dGslab0B
         for (int k = 0; k < 2; ++k) rc |= dCtlB[k].alloc(sizeof(Ctl));
         rc |= dSumTheta.alloc((size_t)N * sizeof(double));
@@ -338,6 +352,7 @@ template <typename real> struct Engine : EngineBase {
             if (int rc2 = dPgTab.alloc(tab.size() * sizeof(double))) return rc2;
             H2D(dPgTab.p, tab.data(), tab.size() * sizeof(double));
         }
+        persist_fault_countdown = (cfg.flags & ERM_FLAG_TEST_PERSIST_TIMEOUT) ? 2 : 0;
         timing.lanes_per_row = W; timing.block_threads = block_threads; timing.grid_blocks = grid_blocks;
         timing.lds_bytes = (int32_t)std::max(lds_pass[0], lds_pass[1]); timing.cu_count = cu_count; timing.persistent = persist ? 1 : 0;
         return configure_kernels();
@@ -372,6 +387,10 @@ template <typename real> struct Engine : EngineBase {
                     HIPCHK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&pass_kernel<M, real, 0, true, true>)));
                     if (fa.sharedSizeBytes > G.lds_static[0]) return fail(ERM_ERR_STATE, "internal: the persistent kernel's static LDS exceeds the planner's figure");
                     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<M, real, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds()));
+                    // every workgroup of a persistent launch must be resident at once: ask the runtime how many fit a compute unit with this block size and LDS
+                    int per_cu = 0;
+                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&pass_kernel<M, real, 0, true, true>), block_threads, fused_lds()));
+                    if ((long long)per_cu * cu_count < grid_blocks) { persist = false; timing.persistent = 0; }
                 }
             }
             if constexpr (fam_cq(M)) {
@@ -418,14 +437,14 @@ template <typename real> struct Engine : EngineBase {
         a.xbuf = dXbuf.as<unsigned long long>(); a.tag0 = 0u; a.tmo = dGcnt.as<unsigned int>() + 2 * n_groups;
         return a;
     }
-    TinyArgs tiny_args(int mode, int first, bool fz = false) const {
+    TinyArgs tiny_args(int mode, bool fz = false) const {
         TinyArgs t{};
         const int o = fz ? 1 - cur : cur;
         t.par = dParB[cur].template as<double>(); t.par_out = dParB[o].template as<double>();
         t.cst = dCst.as<double>(); t.slab0 = dGslab0B[cur].template as<double>(); t.slab1 = dGslab1.as<double>();
         t.ctl = dCtlB[cur].template as<Ctl>(); t.ctl_out = dCtlB[o].template as<Ctl>(); t.ctl_err = dCtlB[0].template as<Ctl>();
         t.tr_item = dTrItem.as<double>(); t.tr_ll = dTrLl.as<double>();
-        t.N = N; t.J = J; t.nFeat = Fk; t.nb0 = n_groups; t.nb1 = n_groups; t.mode = mode; t.first = first;
+        t.N = N; t.J = J; t.nFeat = Fk; t.nb0 = n_groups; t.nb1 = n_groups; t.mode = mode;
         t.intercept = cfg.intercept; t.onepl = cfg.one_pl; t.cov2one = cfg.cov2one; t.sigp_mode = cfg.sigp_mode;
         t.chain = (uint32_t)cfg.chain_id; t.seed = cfg.seed;
         const double q = cfg.q_rt;
@@ -499,9 +518,9 @@ template <typename real> struct Engine : EngineBase {
         return 0;
     }
     // one whole sweep of a single-pass model: tiny step + row pass in one launch; reads buffers [cur], writes [1 - cur]
-    template <int MODEL> int launch_fused(bool first, bool timed) {
+    template <int MODEL> int launch_fused(bool timed) {
         PassArgs<real> a = pass_args(0, 1, true);
-        TinyArgs t = tiny_args(0, first ? 1 : 0, true);
+        TinyArgs t = tiny_args(0, true);
         const bool ev = timed && cfg.profile && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size();
         if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream));
         hipLaunchKernelGGL((pass_kernel<MODEL, real, 0, true>), dim3(grid_blocks), dim3(block_threads), fused_lds(), stream, a, t);
@@ -511,9 +530,9 @@ template <typename real> struct Engine : EngineBase {
         return 0;
     }
     // nsweeps whole sweeps in ONE launch (small data sets): reads buffers [cur] first, alternates inside the launch, leaves cur where nsweeps single launches would
-    template <int MODEL> int launch_persist(int64_t nsweeps, bool first) {
+    template <int MODEL> int launch_persist(int64_t nsweeps) {
         PassArgs<real> a = pass_args(0, 1, true);
-        TinyArgs t = tiny_args(0, first ? 1 : 0, true);
+        TinyArgs t = tiny_args(0, true);
         a.nsweeps = (uint32_t)nsweeps; a.cur0 = (uint32_t)cur;
         if (xtag > 0x7fffffffu - (uint32_t)nsweeps) { HIPCHK(hipMemsetAsync(dXbuf.p, 0, dXbuf.bytes, stream)); xtag = 0; }
         a.tag0 = xtag; xtag += (uint32_t)nsweeps;
@@ -524,30 +543,34 @@ template <typename real> struct Engine : EngineBase {
         cur = (int)((cur + nsweeps) & 1);
         return 0;
     }
-    template <int MODEL, int STEP> int launch_tiny(int mode, int first) {
-        TinyArgs t = tiny_args(mode, first);
+    template <int MODEL, int STEP> int launch_tiny(int mode) {
+        TinyArgs t = tiny_args(mode);
         hipLaunchKernelGGL((tiny_kernel<MODEL, STEP>), dim3(1), dim3(TINY_THREADS), tiny_lds(), stream, t);
         return 0;
     }
 
-    // One sweep = tiny step + row pass (CrossQr: two of each).  Kernel arguments never change between sweeps (sweep / trace-row
-    // counters live in device memory), so a block of GRAPH_SWEEPS sweeps is captured once into a hipGraph and replayed; this
-    // removes the per-launch host overhead that otherwise leaves the GPU idle between the short kernels.
+    // One sweep = tiny step + row pass (CrossQr: two of each).  Kernel arguments never change between sweeps -- the sweep / trace-row counters and the
+    // "first sweep of this call" flag live in device memory (Ctl) -- so EVERY sweep of a run is the same launch sequence: blocks of 32 / 16 / 4 / 2
+    // sweeps are captured once into hipGraphs and replayed, at most one sweep per run is enqueued singly.  That removes the per-launch host overhead
+    // and the idle gaps between singly launched kernels (a 20-sweep erm_run: two graph launches instead of one sweep + four graphs + three sweeps).
 #ifndef ERM_GRAPH_SWEEPS
 #define ERM_GRAPH_SWEEPS 32
 #endif
     static constexpr int GRAPH_SWEEPS = ERM_GRAPH_SWEEPS;
     static constexpr int PROFILE_STRIDE = 8;
-    static constexpr int TAIL_SWEEPS = 4;            // a second, short graph for the remainder of a run (both counts are even: buffer parity)
-    static constexpr int MID_SWEEPS = 16;            // profile mode: the bracketed unit of a short run (a benchmark of a few dozen steps)
-    hipGraphExec_t graph_exec = nullptr, graph_tail = nullptr, graph_mid = nullptr;
+    static constexpr int NGRAPH = 4;
+    // (every count is even: a fused sweep flips the double buffers, and a graph must be replayed with the buffer parity it was captured with -- every
+    // run starts from buffer 0 and replays its graphs BEFORE its one single sweep)
+    const int graph_sweeps[NGRAPH] = {GRAPH_SWEEPS, 16, 4, 2};
+    hipGraphExec_t graphs[NGRAPH] = {nullptr, nullptr, nullptr, nullptr};
+    void drop_graphs() { for (auto& g : graphs) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; } }
     bool ev_calibrated = false; double ev_null_ms = 0.0;
-    template <int MODEL> int enqueue_sweep(bool first, bool timed) {
-        if constexpr (!fam_cq(MODEL)) { if (fused()) return launch_fused<MODEL>(first, timed); }
-        if (int rc = launch_tiny<MODEL, 0>(0, first)) return rc;
+    template <int MODEL> int enqueue_sweep(bool timed) {
+        if constexpr (!fam_cq(MODEL)) { if (fused()) return launch_fused<MODEL>(timed); }
+        if (int rc = launch_tiny<MODEL, 0>(0)) return rc;
         if (int rc = launch_pass<MODEL, 0>(1, timed)) return rc;
         if constexpr (fam_cq(MODEL)) {
-            if (int rc = launch_tiny<MODEL, 1>(0, 0)) return rc;
+            if (int rc = launch_tiny<MODEL, 1>(0)) return rc;
             if (int rc = launch_pass<MODEL, 1>(1, timed)) return rc;
         }
         return 0;
@@ -557,7 +580,7 @@ template <typename real> struct Engine : EngineBase {
         const int cur0 = cur;                        // a fused sweep flips the double buffers while it is being captured: nsw is even, but a
         HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));       // failed capture must not leave the parity changed
         int rc = 0;
-        for (int k = 0; k < nsw && !rc; ++k) rc = enqueue_sweep<MODEL>(false, false);
+        for (int k = 0; k < nsw && !rc; ++k) rc = enqueue_sweep<MODEL>(false);
         const hipError_t e = hipStreamEndCapture(stream, &g);      // always ends the capture, also after a failed enqueue
         if (!rc && e != hipSuccess) rc = fail(ERM_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         if (!rc) {
@@ -581,60 +604,91 @@ template <typename real> struct Engine : EngineBase {
                 // blocks of 2^20 sweeps (packet tags are 32 bits and only grow)
                 for (int64_t done = 0; done < nsweeps; ) {
                     const int64_t nb = std::min<int64_t>(nsweeps - done, 1 << 20);
-                    if (int rc = launch_persist<MODEL>(nb, done == 0)) return rc;
+                    if (int rc = launch_persist<MODEL>(nb)) return rc;
                     done += nb;
                 }
-                if (int rc = launch_tiny<MODEL, 0>(1, 0)) return rc;
+                if (int rc = launch_tiny<MODEL, 0>(1)) return rc;
                 return 0;
             }
         }
-        if (nsweeps > 0) { if (int rc = enqueue_sweep<MODEL>(true, false)) return rc; k = 1; }
         // (a callback exchange synchronises with the host once per pass and cannot be captured; RCCL's all-gather is a stream operation)
         const bool use_graph = exch == nullptr && (cfg.flags & ERM_FLAG_NO_GRAPH) == 0;
-        // profile mode brackets ONE sweep's row pass with events before every replayed block of GRAPH_SWEEPS sweeps (and every
-        // PROFILE_STRIDE-th sweep of the remainder): a live sample of the timed region whose bracketing overhead (~4.6 us per pair)
-        // stays negligible for the whole-job timing, while the bulk of the sweeps still runs from the graph
-        // (TWO single sweeps per block, the first one bracketed: a fused sweep flips the double buffers, and the graph must always be
-        // replayed with the buffer parity it was captured with)
-        const int64_t block = GRAPH_SWEEPS + (cfg.profile ? 2 : 0);
-        // (in profile mode the graph is built by the first run that sweeps at all -- a benchmark's warm-up -- so that capture and
-        // instantiation, a millisecond or two, never fall into a timed run)
-        if (use_graph && !graph_exec && k == 1 && (cfg.profile || nsweeps - k >= block)) {
-            if (int rc = build_graph<MODEL>(GRAPH_SWEEPS, &graph_exec)) return rc;
-            if (int rc = build_graph<MODEL>(TAIL_SWEEPS, &graph_tail)) return rc;
-            if (cfg.profile) { if (int rc = build_graph<MODEL>(MID_SWEEPS, &graph_mid)) return rc; }
-        }
-        if (use_graph && nsweeps - k >= block) {
-            for (; nsweeps - k >= block; k += block) {
-                if (cfg.profile) {
-                    if (int rc = enqueue_sweep<MODEL>(false, true)) return rc;
-                    if (int rc = enqueue_sweep<MODEL>(false, false)) return rc;
+        // profile mode (erm_get_timing: the live kernel time of bench.py's roofline).  Single-pass models: every replayed graph holds launches of the sweep
+        // kernel and nothing else, so the event pairs go around (up to four consecutive) graph launches and every sweep of the run is inside a bracket while
+        // the run still proceeds at graph-replay speed.  The Cross family's sweeps hold tiny kernels too, a sharded sweep its pack kernel and all-gather:
+        // those are bracketed launch by launch on singly enqueued sweeps -- all sweeps of a short run, two (the first one timed; two keep the buffer
+        // parity) before every replayed block of a long one.
+        const bool graph_timing = cfg.profile && !fam_cq(MODEL) && fused() && !sharded();
+        const bool single_timing = cfg.profile && !graph_timing;
+        if (use_graph && !single_timing) {
+            bool open = false;
+            int in_bracket = 0, launches = 0;
+            auto close = [&]() -> int {
+                if (!open) return 0;
+                HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream));
+                ++n_brackets; n_pass_timed += launches; bracket_launches.push_back(launches);
+                open = false; in_bracket = 0; launches = 0;
+                return 0;
+            };
+            for (int gi = 0; gi < NGRAPH; ++gi) {
+                const int nsw = graph_sweeps[gi];
+                while (nsweeps - k >= nsw) {
+                    if (!graphs[gi]) {       // built by the first run that needs it (a benchmark's warm-up), never inside an event bracket
+                        if (int rc = close()) return rc;
+                        if (int rc = build_graph<MODEL>(nsw, &graphs[gi])) return rc;
+                    }
+                    if (graph_timing && !open && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size()) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream)); open = true; }
+                    HIPCHK(hipGraphLaunch(graphs[gi], stream));
+                    k += nsw; launches += nsw; ++in_bracket;
+                    if (in_bracket >= 4) { if (int rc = close()) return rc; }
                 }
-                HIPCHK(hipGraphLaunch(graph_exec, stream));
+            }
+            if (int rc = close()) return rc;
+        } else if (use_graph && nsweeps >= 2 * (GRAPH_SWEEPS + 2)) {
+            for (; nsweeps - k >= GRAPH_SWEEPS + 2; k += GRAPH_SWEEPS + 2) {
+                if (int rc = enqueue_sweep<MODEL>(true)) return rc;
+                if (int rc = enqueue_sweep<MODEL>(false)) return rc;
+                if (!graphs[0]) { if (int rc = build_graph<MODEL>(GRAPH_SWEEPS, &graphs[0])) return rc; }
+                HIPCHK(hipGraphLaunch(graphs[0], stream));
             }
         }
-        // a SHORT profiled run (a benchmark of a few dozen steps) brackets every one of its sweeps instead, so that the kernel time it
-        // reports is an average over the whole timed region, not one sample
-        // (fused models: in brackets of one replayed TAIL_SWEEPS-sweep graph each -- TAIL_SWEEPS launches of the sweep kernel and nothing else
-        // per event pair -- so that the benchmark still runs at graph-replay speed; the Cross family's sweeps hold tiny kernels too and are
-        // bracketed launch by launch)
-        const bool bracket_all = cfg.profile && nsweeps < 2 * block;
-        if (use_graph && graph_tail && k >= 1) {
-            const bool in_graph = bracket_all && !fam_cq(MODEL) && fused() && !sharded();
-            if (in_graph || !bracket_all) {
-                auto replay = [&](hipGraphExec_t g, int nsw) -> int {
-                    const bool ev = in_graph && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size();
-                    if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream));
-                    HIPCHK(hipGraphLaunch(g, stream));
-                    if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; n_pass_timed += nsw; bracket_launches.push_back(nsw); }
-                    return 0;
-                };
-                if (in_graph && graph_mid) { for (; nsweeps - k >= MID_SWEEPS; k += MID_SWEEPS) { if (int rc = replay(graph_mid, MID_SWEEPS)) return rc; } }
-                for (; nsweeps - k >= TAIL_SWEEPS; k += TAIL_SWEEPS) { if (int rc = replay(graph_tail, TAIL_SWEEPS)) return rc; }
-            }
-        }
-        for (int64_t r = 0; k < nsweeps; ++k, ++r) { if (int rc = enqueue_sweep<MODEL>(false, bracket_all || (r % PROFILE_STRIDE) == 0)) return rc; }
-        if (nsweeps > 0 || !stats_valid) { if (int rc = launch_tiny<MODEL, 0>(1, nsweeps == 0)) return rc; }
+        const bool short_run = nsweeps < 2 * (GRAPH_SWEEPS + 2);
+        for (int64_t r = 0; k < nsweeps; ++k, ++r) { if (int rc = enqueue_sweep<MODEL>(graph_timing || (single_timing && (short_run || (r % PROFILE_STRIDE) == 0)))) return rc; }
+        if (int rc = launch_tiny<MODEL, 0>(1)) return rc;      // the log-likelihood of the last sweep (a call without sweeps: nothing to reduce, the step returns at once)
+        return 0;
+    }
+
+    // ---- the state an erm_run changes in place (persistent launches save it first: a launch that times out is replayed per sweep from the copy).
+    // Counters and tickets are re-initialised by every run, trace rows >= rows_done are simply written again, and the host's own counters move only
+    // after a run has succeeded; what is left: theta, zeta, omega, LatentQr's nu, the parameter block and statistics of buffer 0 (every run starts
+    // there), and the post-burn-in sums.
+    template <typename Fn> void snap_each(Fn&& f) const {
+        f(dTheta); if (is_rt()) f(dZeta);
+        f(dOmega); if (cfg.model == ERM_MODEL_LATENTQR) f(dNu);
+        f(dParB[0]); f(dGslab0B[0]);
+        f(dSumTheta); if (is_rt()) f(dSumZeta); if (dSumNu.p) f(dSumNu);
+    }
+    size_t snap_bytes() const {
+        // (called before the buffers exist: sizes from the configuration)
+        const size_t NJ = (size_t)N * J, r = sizeof(real);
+        size_t b = (size_t)N * r + (is_rt() ? (size_t)N * r : 0) + NJ * r + (cfg.model == ERM_MODEL_LATENTQR ? (size_t)N * r : 0);
+        b += (size_t)par_size(J) * 8 + (size_t)std::max(n_groups, GROUP) * ns[0] * 8;
+        b += (size_t)N * 8 + (is_rt() ? (size_t)N * 8 : 0) + (cfg.model == ERM_MODEL_LATENTQR ? (size_t)N * 8 : 0);
+        return b + 10 * 256;                         // every segment starts on a 256-byte boundary
+    }
+    int snap_copy(bool restore) {
+        CopySegs S{};
+        size_t off = 0;
+        bool ok = true;
+        snap_each([&](const DevBuf& d) {
+            if (S.n >= 10 || off + d.bytes > dSnap.bytes) { ok = false; return; }
+            char* sp = dSnap.as<char>() + off;
+            S.src[S.n] = restore ? (const void*)sp : (const void*)d.p; S.dst[S.n] = restore ? d.p : (void*)sp; S.bytes[S.n] = d.bytes; ++S.n;
+            off = (off + d.bytes + 255) & ~(size_t)255;
+        });
+        if (!ok) return fail(ERM_ERR_STATE, "internal: the persistent launch's snapshot buffer is too small");
+        hipLaunchKernelGGL(copy_segments_kernel, dim3(256), dim3(256), 0, stream, S);
+        HIPCHK(hipGetLastError());
         return 0;
     }
 
@@ -642,14 +696,24 @@ template <typename real> struct Engine : EngineBase {
     // stream is drained, the buffer parity reset, and the engine refuses to continue until the caller installs a state again.
     bool poisoned = false;
     bool stats_valid = false;                        // omega_{t+1} (nu_{t+1}) and the statistics of the CURRENT state are resident (set by a completed run)
-    Ctl* host_ctl = nullptr;                         // pinned: [0] upload, [1], [2] read-back of the two device copies
+    Ctl* host_ctl = nullptr;                         // pinned: [1], [2] the two device copies of the counters, [3] the time-out word (run_end_kernel stores them)
+    Ctl* host_ctl_dev = nullptr;                     // the same memory as the device addresses it
     bool has_stats_state() const { return host_ctl != nullptr; }
     int run(int64_t nsweeps) override {
         if (!has_data) return fail(ERM_ERR_STATE, "erm_set_data has not been called");
         if (poisoned) return fail(ERM_ERR_STATE, "a previous erm_run failed part-way: call erm_set_state (and erm_reset_trace) before running again");
         if (nsweeps < 0) return fail(ERM_ERR_ARG, "nsweeps must be non-negative");
         if (rows_done + nsweeps > rows_cap) return fail(ERM_ERR_ARG, "trace capacity exceeded: n_iter*n_chain rows were allocated");
-        const int rc = run_checked(nsweeps);
+        int rc = run_checked(nsweeps);
+        if (rc == ERM_PERSIST_TIMEOUT) {
+            // the persistent launch never had all its workgroups resident (another process holds compute units): every workgroup has left the launch;
+            // put back what the call found, leave the persistent schedule for good and run the call again, one launch per sweep at the same geometry
+            // (bit for bit the chain the persistent launch would have produced)
+            persist = false; timing.persistent = 0; ++timing.persist_fallbacks;
+            rc = snap_copy(true);
+            if (rc == 0) { cur = 0; stats_valid = snap_stats_valid; rc = run_checked(nsweeps); }
+            if (rc == ERM_PERSIST_TIMEOUT) rc = fail(ERM_ERR_STATE, "internal: persistent time-out reported by a per-sweep run");
+        }
         if (rc != 0 && rc != ERM_ERR_NONFINITE) {
             const std::string msg = g_err;            // keep the first error's message
             (void)hipStreamSynchronize(stream);
@@ -661,19 +725,24 @@ template <typename real> struct Engine : EngineBase {
         }
         return rc;
     }
+    static constexpr int ERM_PERSIST_TIMEOUT = -1000;      // internal: run_checked -> run
     int run_checked(int64_t nsweeps) {
         HIPCHK(hipSetDevice(cfg.device));
         if (sharded() || !has_stats_state()) stats_valid = false;
-        Ctl& c = host_ctl[0];                        // pinned: the uploads below are genuinely asynchronous
-        c = Ctl{};
+        Ctl c{};
         c.sweep = sweeps_total; c.row = (uint32_t)rows_done; c.burn_rows = (uint32_t)((int64_t)cfg.n_burnin * cfg.n_chain); c.err = 0;
         if (cur == 1) {      // every run starts from buffer 0 so that a captured graph always replays with the buffer parity it was built with
             HIPCHK(hipMemcpyAsync(dParB[0].p, dParB[1].p, dParB[0].bytes, hipMemcpyDeviceToDevice, stream));
             if (stats_valid) HIPCHK(hipMemcpyAsync(dGslab0B[0].p, dGslab0B[1].p, dGslab0B[0].bytes, hipMemcpyDeviceToDevice, stream));
             cur = 0;
         }
-        for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpyAsync(dCtlB[k].p, &c, sizeof(Ctl), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemsetAsync(dGcnt.p, 0, dGcnt.bytes, stream));
+        const bool persistent_run = persist && !sharded() && nsweeps > 0 && !m_cq();
+        // counters, tickets, the persistent launch's wait bound (1 s of the 100 MHz wall clock; 2 ms under the test hook) in ONE small launch
+        const bool fault = persistent_run && persist_fault_countdown > 0 && --persist_fault_countdown == 0;
+        hipLaunchKernelGGL(run_begin_kernel, dim3(1), dim3(256), 0, stream, dCtlB[0].template as<Ctl>(), dCtlB[1].template as<Ctl>(), c, dGcnt.as<unsigned int>(), 2 * n_groups + 4,
+                           fault ? 200000u : 100000000u, fault ? 1u : 0u);
+        HIPCHK(hipGetLastError());
+        if (persistent_run) { snap_stats_valid = stats_valid; if (int rc = snap_copy(false)) return rc; }
         n_pass_timed = 0; n_brackets = 0; bracket_launches.clear();
         const bool calibrate = cfg.profile && pass_ev.size() >= 64 && !ev_calibrated;
         if (calibrate) {   // empty event pairs, once per engine: the bracketing overhead that is subtracted from every timed launch
@@ -681,19 +750,23 @@ template <typename real> struct Engine : EngineBase {
         }
         // persistent launches of one process take turns on a device (see g_persist_mu); held until the stream has drained
         std::unique_lock<std::mutex> turn;
-        if (persist && !sharded() && nsweeps > 0) turn = std::unique_lock<std::mutex>(g_persist_mu[(unsigned)cfg.device % 64u]);
+        if (persistent_run) turn = std::unique_lock<std::mutex>(g_persist_mu[(unsigned)cfg.device % 64u]);
         HIPCHK(hipEventRecord(ev0, stream));
         if (int rc = dispatch([&](auto m) -> int { return run_model<decltype(m)::value>(nsweeps); })) return rc;
         HIPCHK(hipEventRecord(ev1, stream));
         HIPCHK(hipGetLastError());
-        for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpyAsync(&host_ctl[1 + k], dCtlB[k].p, sizeof(Ctl), hipMemcpyDeviceToHost, stream));
-        unsigned int* h_tmo = reinterpret_cast<unsigned int*>(&host_ctl[3]);
+        // the counters of both buffers and the time-out word, stored into pinned host memory by one small launch (no copy operations)
+        volatile unsigned int* h_tmo = reinterpret_cast<volatile unsigned int*>(&host_ctl[3]);
         *h_tmo = 0u;
-        if (persist) HIPCHK(hipMemcpyAsync(h_tmo, dGcnt.as<unsigned int>() + 2 * n_groups, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(run_end_kernel, dim3(1), dim3(64), 0, stream, dCtlB[0].template as<Ctl>(), dCtlB[1].template as<Ctl>(), dGcnt.as<unsigned int>() + 2 * n_groups,
+                           host_ctl_dev + 1, reinterpret_cast<unsigned int*>(host_ctl_dev + 3));
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         if (turn.owns_lock()) turn.unlock();
-        if (*h_tmo != 0u) return fail(ERM_ERR_STATE, "the persistent sweep kernel timed out waiting for another workgroup's statistics (its workgroups were not all "
-                                                     "resident: another persistent kernel holds the device?); re-create the engine with ERM_FLAG_NO_PERSIST");
+        if (*h_tmo != 0u) {
+            g_err = "the persistent sweep kernel timed out waiting for another workgroup's statistics (its workgroups were not all resident)";
+            return ERM_PERSIST_TIMEOUT;
+        }
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
         timing.run_ms = ms; timing.sweeps = nsweeps; timing.pass_ms_total = 0.0; timing.pass_launches = n_pass_timed;
@@ -1163,7 +1236,10 @@ template <typename real> struct Engine : EngineBase {
     }
 
     // ess / rhat of every column of Post.ra / rt / qr, computed on the device from the resident traces (diag_kernel)
-    int get_diagnostics(int which, double* ess, double* rhat) override {
+    // ess / rhat of every column of trace `which` into device arrays of trace_width(which) doubles.  GibbsRtIrtCrossQr's vec(nu) block of Post.qr is
+    // column-major N x J in Julia's layout and row-major on the device: it is diagnosed in DEVICE order (entry q + i * J + j), *nu_block says so.
+    int diag_device(int which, DevBuf& dE, DevBuf& dR, bool* nu_block) {
+        *nu_block = false;
         HIPCHK(hipSetDevice(cfg.device));
         const int64_t wd = trace_width(which);
         if (which == ERM_TRACE_LOGLIKE || wd <= 0) return fail(ERM_ERR_ARG, "diagnostics exist for the ra / rt / qr traces");
@@ -1173,7 +1249,6 @@ template <typename real> struct Engine : EngineBase {
         if (Tn / 2 < 4) return fail(ERM_ERR_ARG, "too few post-burn-in iterations for split-chain diagnostics (need >= 8)");
         if (2 * cfg.n_chain > DIAG_MAXSEQ) return fail(ERM_ERR_ARG, "too many chains for the diagnostics kernel");
         HIPCHK(hipStreamSynchronize(stream));
-        DevBuf dE, dR;
         if (int rc = dE.alloc((size_t)wd * sizeof(double))) return rc;
         if (int rc = dR.alloc((size_t)wd * sizeof(double))) return rc;
         auto launch_real = [&](const DevBuf& tr, int64_t ncol, int64_t off) -> int {
@@ -1205,28 +1280,45 @@ template <typename real> struct Engine : EngineBase {
             if (int rc = launch_item(4 * J, q, 0)) return rc;
             if (cfg.model == ERM_MODEL_LATENTQR) { if (int rc = launch_real(dTrNu, N, q)) return rc; }
             if (cfg.model == ERM_MODEL_CROSSQR) {
-                // vec(nu) in Post.qr is column-major N x J; the device trace is row-major: diagnose in device order, permute on the host
                 if (!dTrNu.p) return fail(ERM_ERR_NOTRACE, "the per-sweep nu trace was not recorded (erm_config.nu_trace_max_gb)");
-                DevBuf e2, r2;
-                if (int rc = e2.alloc((size_t)N * J * sizeof(double))) return rc;
-                if (int rc = r2.alloc((size_t)N * J * sizeof(double))) return rc;
-                hipLaunchKernelGGL((diag_kernel<real>), dim3((unsigned)(((int64_t)N * J + 255) / 256)), dim3(256), 0, stream, dTrNu.as<real>(), (long long)N * J,
-                                   (long long)N * J, cfg.n_iter, cfg.n_chain, cfg.n_burnin, e2.as<double>(), r2.as<double>());
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(stream));
-                std::vector<double> he((size_t)N * J), hr((size_t)N * J);
-                HIPCHK(hipMemcpy(he.data(), e2.p, he.size() * sizeof(double), hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(hr.data(), r2.p, hr.size() * sizeof(double), hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(ess, dE.p, (size_t)q * sizeof(double), hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(rhat, dR.p, (size_t)q * sizeof(double), hipMemcpyDeviceToHost));
-                for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) { ess[q + i + N * j] = he[(size_t)i * J + j]; rhat[q + i + N * j] = hr[(size_t)i * J + j]; }
-                return 0;
+                if (int rc = launch_real(dTrNu, (int64_t)N * J, q)) return rc;
+                *nu_block = true;
             }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    // ess / rhat of every column of Post.ra / rt / qr, computed on the device from the resident traces (diag_kernel)
+    int get_diagnostics(int which, double* ess, double* rhat) override {
+        DevBuf dE, dR;
+        bool nu_block = false;
+        if (int rc = diag_device(which, dE, dR, &nu_block)) return rc;
+        const int64_t wd = trace_width(which);
         HIPCHK(hipMemcpy(ess, dE.p, (size_t)wd * sizeof(double), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(rhat, dR.p, (size_t)wd * sizeof(double), hipMemcpyDeviceToHost));
+        if (nu_block) {      // device order (row-major N x J) -> Julia's vec(nu) (column-major)
+            const int q = nq();
+            std::vector<double> he(ess + q, ess + wd), hr(rhat + q, rhat + wd);
+            for (int j = 0; j < J; ++j) for (int64_t i = 0; i < N; ++i) { ess[q + i + N * j] = he[(size_t)i * J + j]; rhat[q + i + N * j] = hr[(size_t)i * J + j]; }
+        }
+        return 0;
+    }
+    // checkConvergence's summary (src/SimTools.jl:419-443) without the N-wide vectors: counts of the columns with a defined ESS / R-hat and of those with
+    // ESS > 400 / R-hat < 1.1 (the reference's thresholds), counted on the device
+    int get_convergence(int which, int64_t* c4) override {
+        DevBuf dE, dR, dC;
+        bool nu_block = false;
+        if (int rc = diag_device(which, dE, dR, &nu_block)) return rc;
+        if (int rc = dC.alloc(4 * sizeof(unsigned long long))) return rc;
+        const int64_t wd = trace_width(which);
+        hipLaunchKernelGGL(diag_count_kernel, dim3((unsigned)std::min<int64_t>((wd + 255) / 256, 1024)), dim3(256), 0, stream, dE.as<double>(), dR.as<double>(), (long long)wd, 400.0, 1.1,
+                           dC.as<unsigned long long>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        unsigned long long h[4];
+        HIPCHK(hipMemcpy(h, dC.p, sizeof(h), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 4; ++k) c4[k] = (int64_t)h[k];
         return 0;
     }
 
@@ -1285,21 +1377,78 @@ template <typename real> struct Engine : EngineBase {
     int64_t summary_len() const override { return item_trace_width() + N + (is_rt() ? N : 0) + nu_len(); }
     int summary_add(double* acc) override {
         HIPCHK(hipSetDevice(cfg.device));
-        std::vector<double> m;
-        if (int rc = item_sums(m)) return rc;
-        DevBuf tmp;
-        if (int rc = tmp.alloc(m.size() * sizeof(double))) return rc;
-        HIPCHK(hipMemcpyAsync(tmp.p, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         auto add = [&](double* dst, const double* src, int64_t n) {
             hipLaunchKernelGGL(acc_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, dst, src, (long long)n);
         };
-        int64_t o = 0;
-        add(acc, tmp.as<double>(), (int64_t)m.size()); o += (int64_t)m.size();
+        // item-level columns: summed over the post-burn-in rows of the resident item trace ON the device, in row order (the order erm_get_mean's host sum uses)
+        const int64_t wi = item_trace_width(), burn = (int64_t)cfg.n_burnin * cfg.n_chain;
+        hipLaunchKernelGGL(item_sum_kernel, dim3((unsigned)((wi + 255) / 256)), dim3(256), 0, stream, dTrItem.as<double>(), (long long)wi, (long long)std::min(burn, rows_done), (long long)rows_done, acc);
+        int64_t o = wi;
         add(acc + o, dSumTheta.as<double>(), N); o += N;
         if (is_rt()) { add(acc + o, dSumZeta.as<double>(), N); o += N; }
         if (nu_len() > 0) add(acc + o, dSumNu.as<double>(), nu_len());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(stream));          // tmp dies here
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    // ---- DIC from device-resident state (include/ertirt.h, erm_get_dic)
+    int loglik_at(const double* dsum, double inv, double* ll) override {
+        if (!has_data) return fail(ERM_ERR_STATE, "no data set is resident");
+        HIPCHK(hipSetDevice(cfg.device));
+        const int nb = (int)std::min<int64_t>(1024, (N + 63) / 64);
+        DevBuf dPart;
+        if (int rc = dPart.alloc((size_t)nb * sizeof(double))) return rc;
+        LogLikArgs D{};
+        D.Y = dY.as<uint8_t>(); D.C = dC.p; D.X = dX.p; D.cm = dCst.as<double>() + cst_off_m(J);
+        D.sum = dsum; D.inv = inv; D.N = N; D.J = J; D.F = Fk; D.model = cfg.model;
+        const int64_t wi = item_trace_width();
+        D.off_theta = wi; D.off_zeta = is_rt() ? wi + N : -1; D.off_nu = nu_len() > 0 ? wi + N + (is_rt() ? N : 0) : -1;
+        const double q = cfg.q_rt;
+        D.k1 = m_nu() ? (1.0 - 2.0 * q) / (q * (1.0 - q)) : 0.0; D.k2 = m_nu() ? 2.0 / (q * (1.0 - q)) : 1.0;
+        D.rows_per_block = (N + nb - 1) / nb; D.part = dPart.as<double>();
+        const size_t lds = ((size_t)5 * J + 4 + 2 * PMAX) * sizeof(double);
+        hipLaunchKernelGGL((loglik_kernel<real>), dim3(nb), dim3(256), lds, stream, D);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<double> part(nb);
+        HIPCHK(hipMemcpy(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double t = 0.0;
+        for (double v : part) t += v;
+        *ll = t;
+        return 0;
+    }
+    int ll_trace_sum(double* out) override {
+        HIPCHK(hipSetDevice(cfg.device));
+        DevBuf d;
+        if (int rc = d.alloc(sizeof(double))) return rc;
+        hipLaunchKernelGGL(ll_trace_sum_kernel, dim3(1), dim3(256), 0, stream, dTrLl.as<double>(), (long long)rows_done, d.as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipMemcpy(out, d.p, sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    int get_dic(double* out4) override {
+        if (poisoned) return fail(ERM_ERR_STATE, "a previous erm_run failed part-way: the state is undefined until erm_set_state");
+        if (sharded()) return fail(ERM_ERR_STATE, "erm_get_dic is not available on a shard (the log-likelihood at Post.mean needs every subject)");
+        if (rows_done <= 0 || post_rows <= 0) return fail(ERM_ERR_STATE, "no post-burn-in sweeps recorded");
+        HIPCHK(hipSetDevice(cfg.device));
+        DevBuf acc;
+        if (int rc = acc.alloc((size_t)summary_len() * sizeof(double))) return rc;
+        if (int rc = summary_add(acc.as<double>())) return rc;
+        double ll_hat = 0.0, ll_sum = 0.0;
+        if (int rc = loglik_at(acc.as<double>(), 1.0 / (double)post_rows, &ll_hat)) return rc;
+        if (int rc = ll_trace_sum(&ll_sum)) return rc;
+        const double Dhat = -2.0 * ll_hat, Dbar = -2.0 * ll_sum / (double)rows_done;
+        out4[0] = Dbar; out4[1] = Dhat; out4[2] = Dbar - Dhat; out4[3] = Dbar + (Dbar - Dhat);
+        return 0;
+    }
+    int set_seed(uint64_t seed) override {
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamSynchronize(stream));
+        cfg.seed = seed;
+        drop_graphs();               // the captured launches carry the seed as a kernel argument
+        stats_valid = false;         // the resident omega_{t+1} / nu_{t+1} were drawn from the old streams: the next run draws them again
         return 0;
     }
     int summary_unpack(const double* mean, erm_state* out) const override {
@@ -1433,6 +1582,9 @@ int erm_simulate_data(erm_handle h, const erm_state* truth, uint64_t seed, int n
 int erm_get_data(erm_handle h, uint8_t* Y, double* logT, double* X) { CHK_H; return h->e->get_data(Y, logT, X); }
 int erm_get_truth(erm_handle h, double* theta, double* zeta) { CHK_H; return h->e->get_truth(theta, zeta); }
 int erm_get_diagnostics(erm_handle h, int which, double* ess, double* rhat) { CHK_H; if (!ess || !rhat) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_diagnostics(which, ess, rhat); }
+int erm_get_convergence(erm_handle h, int which, int64_t* counts4) { CHK_H; if (!counts4) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_convergence(which, counts4); }
+int erm_get_dic(erm_handle h, double* out4) { CHK_H; if (!out4) return fail(ERM_ERR_ARG, "out is NULL"); return h->e->get_dic(out4); }
+int erm_set_seed(erm_handle h, uint64_t seed) { CHK_H; return h->e->set_seed(seed); }
 int erm_get_timing(erm_handle h, erm_timing* out) { CHK_H; if (!out) return fail(ERM_ERR_ARG, "out is NULL"); *out = h->e->timing; return 0; }
 int erm_set_shard(erm_handle h, int rank, int count, int64_t n_subj_total, int64_t row_base, erm_exchange_fn exchange, void* user)
 {
@@ -1552,17 +1704,16 @@ int erm_farm_get_trace(erm_farm_handle f, int which, double* out)
     const int64_t blk = (int64_t)f->cfg.n_iter * wd;
     return f->parallel([&](int l) { return f->eng[l]->e->get_trace(which, out + (size_t)l * blk); });
 }
-int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
+// The farm's one collective: every chain's post-burn-in sums added into its device's accumulator (chains that share a device add in chain order), the
+// devices' vectors summed by ONE ncclAllReduce (RCCL over xGMI), each rank on a stream of its own.  Leaves the total on every device (acc[d]) and returns the
+// number of post-burn-in rows.  ERM_FLAG_FARM_FORCE_RCCL takes the RCCL path with a one-device communicator too (tests).
+static int farm_reduce(erm_farm_handle f, std::vector<DevBuf>& acc, int64_t* total_out, double* init_ms_out)
 {
-    CHK_F;
-    if (!out) return fail(ERM_ERR_ARG, "state is NULL");
-    const auto t0 = std::chrono::steady_clock::now();
     const int64_t total = erm_farm_post_count(f);
     if (total <= 0) return fail(ERM_ERR_STATE, "no post-burn-in sweeps recorded");
     const int64_t len = f->eng[0]->e->summary_len();
     const int nd = (int)f->udev.size();
-    // per-device accumulators: the chains of a device add their sums in chain order
-    std::vector<DevBuf> acc(nd);
+    acc.clear(); acc.resize(nd);
     for (int d = 0; d < nd; ++d) {
         HIPCHK(hipSetDevice(f->udev[d]));
         if (int rc = acc[d].alloc((size_t)len * sizeof(double))) return rc;      // zeroed, complete on return
@@ -1572,12 +1723,10 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
         while (f->udev[d] != f->dev[l]) ++d;
         if (int rc = f->eng[l]->e->summary_add(acc[d].as<double>())) return fail(rc, "chain " + std::to_string(l) + ": " + g_err);      // synchronises its stream
     }
-    // one all-reduce over the devices (RCCL over xGMI), each rank on a stream of its own.  ERM_FLAG_FARM_FORCE_RCCL takes this path with a
-    // one-device communicator too (tests)
     const bool force = (f->cfg.flags & ERM_FLAG_FARM_FORCE_RCCL) != 0;
     f->used_rccl = false;
     f->tm.allreduce_ms = 0.0;
-    double init_ms = 0.0;                     // communicator creation inside THIS call (first reduction only): reported apart from gather_ms
+    *init_ms_out = 0.0;                       // communicator creation inside THIS call (first reduction only): reported apart from gather_ms
     if (nd > 1 || force) {
         if (int rc = g_rccl.load()) return rc;
         if (f->rstream.empty()) {
@@ -1590,7 +1739,7 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
             const ncclResult_t r = g_rccl.CommInitAll(f->comms.data(), nd, f->udev.data());
             if (r != ncclSuccess) { f->comms.clear(); return fail(ERM_ERR_STATE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
             f->tm.comm_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
-            init_ms = f->tm.comm_init_ms;
+            *init_ms_out = f->tm.comm_init_ms;
         }
         const auto a0 = std::chrono::steady_clock::now();
         // a group that has been started is always ended, whatever happens inside it
@@ -1609,6 +1758,19 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
         f->tm.allreduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count();
         f->used_rccl = true;
     }
+    *total_out = total;
+    return 0;
+}
+int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
+{
+    CHK_F;
+    if (!out) return fail(ERM_ERR_ARG, "state is NULL");
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<DevBuf> acc;
+    int64_t total = 0;
+    double init_ms = 0.0;
+    if (int rc = farm_reduce(f, acc, &total, &init_ms)) return rc;
+    const int64_t len = f->eng[0]->e->summary_len();
     std::vector<double> m((size_t)len);
     HIPCHK(hipSetDevice(f->udev[0]));
     HIPCHK(hipMemcpy(m.data(), acc[0].p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost));
@@ -1618,9 +1780,51 @@ int erm_farm_get_mean(erm_farm_handle f, erm_state* out)
     f->tm.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - init_ms;
     return rc;
 }
+// getDic of the farm: Dbar over the logLike rows of ALL chains, Dhat at the joint Post.mean -- the vector erm_farm_get_mean reduces, evaluated where it lies
+// (the first chain's device and data copy; every chain holds the same data set); only the four numbers cross the boundary
+int erm_farm_get_dic(erm_farm_handle f, double* out4)
+{
+    CHK_F;
+    if (!out4) return fail(ERM_ERR_ARG, "out is NULL");
+    std::vector<DevBuf> acc;
+    int64_t total = 0;
+    double init_ms = 0.0;
+    if (int rc = farm_reduce(f, acc, &total, &init_ms)) return rc;
+    int d0 = 0;
+    while (f->udev[d0] != f->dev[0]) ++d0;
+    double ll_hat = 0.0;
+    if (int rc = f->eng[0]->e->loglik_at(acc[d0].as<double>(), 1.0 / (double)total, &ll_hat)) return rc;
+    double ll_sum = 0.0; int64_t rows = 0;
+    for (auto& e : f->eng) { double t = 0.0; if (int rc = e->e->ll_trace_sum(&t)) return rc; ll_sum += t; rows += e->e->rows_done; }
+    if (rows <= 0) return fail(ERM_ERR_STATE, "no sweeps recorded");
+    const double Dhat = -2.0 * ll_hat, Dbar = -2.0 * ll_sum / (double)rows;
+    out4[0] = Dbar; out4[1] = Dhat; out4[2] = Dbar - Dhat; out4[3] = Dbar + (Dbar - Dhat);
+    return 0;
+}
+int erm_farm_set_seed(erm_farm_handle f, uint64_t seed)
+{
+    CHK_F;
+    for (auto& e : f->eng) if (int rc = e->e->set_seed(seed)) return rc;
+    return 0;
+}
 
 const char* erm_last_error(void) { return g_err.c_str(); }
-const char* erm_version(void) { return "ertirt-amd 0.1.0 (gfx950)"; }
+const char* erm_version(void) { return "ertirt-amd 0.4.0 (gfx950)"; }
+int erm_abi_version(void) { return ERM_ABI_VERSION; }
+
+int erm_debug_invwishart(int device, uint64_t seed, uint32_t sweep, int64_t n, double nu, const double* psi4, double* out)
+{
+    if (n <= 0 || !out || !psi4) return fail(ERM_ERR_ARG, "bad n / psi / out");
+    if (!(nu > 1.0) || !(psi4[0] > 0.0) || !(psi4[0] * psi4[3] - psi4[1] * psi4[2] > 0.0)) return fail(ERM_ERR_ARG, "InverseWishart(nu, Psi) needs nu > 1 and a positive definite Psi");
+    HIPCHK(hipSetDevice(device));
+    DevBuf dout;
+    if (int rc = dout.alloc((size_t)n * 4 * sizeof(double))) return rc;
+    hipLaunchKernelGGL(invwishart_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, seed, sweep, (long long)n, nu, psi4[0], psi4[1], psi4[2], psi4[3], dout.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout.p, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32_t site, uint32_t sweep, int64_t n,
                      const double* par0, const double* par1, double* out)

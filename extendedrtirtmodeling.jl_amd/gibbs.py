@@ -44,6 +44,8 @@ class _GibbsBase:
         self.precision = precision
         self.trace = trace
         self.chain_id = int(chain_id)
+        if not 0 <= self.chain_id <= 255:
+            raise ValueError("chain_id must be in 0 .. 255 (the random streams carry eight bits of it)")
         # shard = (rank, count, nSubjTotal, rowBase, transport): this process holds subjects [rowBase, rowBase + Cond.nSubj) of ONE chain
         # spread over `count` devices (include/ertirt.h erm_set_shard*); transport = the 128-byte id of _lib.rccl_unique_id() (the
         # library's in-stream RCCL all-gather) or a callable exchange(send_ptr, recv_ptr, nbytes) such as parallel.TorchExchange.
@@ -53,6 +55,7 @@ class _GibbsBase:
         self._engine = None
         self._engine_key = None
         self._data_on_device = False
+        self.farm = None
         self.Para = None
         self.setInitialValues()          # constructors always overwrite Para (src/GibbsRtIrt.pl.jl:100-102)
         if shard is not None:
@@ -198,14 +201,18 @@ class _GibbsBase:
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+        if getattr(self, "farm", None) is not None:
+            self.farm.close()
+            self.farm = None
 
 
-def simulateData(MCMC: _GibbsBase, truePara: InputPara, *, type="norm", seed=4321, pull=True):
+def simulateData(MCMC: _GibbsBase, truePara: InputPara, *, type="norm", seed=4321, pull=True, pull_truth=True, intercept=False, itemtype="2pl", cov2one=None):
     """setData* on the device (erm_simulate_data): generates X, theta, zeta, Y, logT from `truePara` straight into the engine's
-    resident buffers -- no host generation, no upload.  truePara.theta / .zeta receive the generated truth; with pull=True the data set is
-    also copied to MCMC.Data (needed by the host-side getDic / getLogLikelihood)."""
+    resident buffers -- no host generation, no upload.  truePara.theta / .zeta receive the generated truth (pull_truth=False leaves it on the
+    device); with pull=True the data set is also copied to MCMC.Data (the host-side getLogLikelihood / getDicHost need it; getDic does not)."""
     from .base import InputData
-    eng = MCMC._engine_for(False, False, MCMC._cov2one_default, upload=False)
+    # (the engine is keyed by the sample! kwargs: give the ones the following sample! will use, or the data set is carried over through the host)
+    eng = MCMC._engine_for(intercept, itemtype == "1pl", MCMC._cov2one_default if cov2one is None else cov2one, upload=False)
     noise = {"norm": 0, "tail": 1, "skew": 2}[type]
     truth = dict(a=truePara.a, b=truePara.b)
     if MCMC._model != _lib.MODEL_MLIRT:
@@ -216,7 +223,9 @@ def simulateData(MCMC: _GibbsBase, truePara: InputPara, *, type="norm", seed=432
         truth["beta"] = np.asarray(truePara.beta, dtype=np.float64).reshape(-1, order="F")
     if truePara.rho.size:
         truth["rho"] = truePara.rho
-    truePara.theta, truePara.zeta = eng.simulate_data(seed=seed, noise=noise, **truth)
+    tz = eng.simulate_data(seed=seed, noise=noise, pull_truth=pull_truth, **truth)
+    if pull_truth:
+        truePara.theta, truePara.zeta = tz
     MCMC.truePara = truePara
     MCMC._data_on_device = True
     if pull:
@@ -261,11 +270,13 @@ def _sample_farm(MCMC: _GibbsBase, intercept, onepl, cov2one, devices):
     return MCMC
 
 
-def sample_b(MCMC: _GibbsBase, *, intercept=False, itemtype="2pl", cov2one=None, devices=None):
+def sample_b(MCMC: _GibbsBase, *, intercept=False, itemtype="2pl", cov2one=None, devices=None, fill=True):
     """sample!(MCMC; intercept, itemtype, cov2one) -- src/GibbsRtIrt.pl.jl:210,278; Cross :265; Latent :271.
     Runs Cond.nIter * Cond.nChain sweeps (the reference's interleaved `for m in 1:nIter, l in 1:nChain` loop over ONE
     shared Para), fills MCMC.Post, leaves the final state in MCMC.Para and returns MCMC.
-    devices = [gpu ordinals]: the nChain chains become INDEPENDENT chains farmed over those GPUs instead (see _sample_farm)."""
+    devices = [gpu ordinals]: the nChain chains become INDEPENDENT chains farmed over those GPUs instead (see _sample_farm).
+    fill = False leaves Post and Para untouched: traces, running means and the final state stay on the device, where getDic,
+    checkConvergence and MCMC._engine.get_mean(which) read them (runSimulation's replications cross the boundary with summaries only)."""
     if itemtype not in ("1pl", "2pl"):
         raise ValueError("Invalid input: the item type must be '1pl' or '2pl'.")   # same text as :213,281
     if cov2one is None:
@@ -274,12 +285,16 @@ def sample_b(MCMC: _GibbsBase, *, intercept=False, itemtype="2pl", cov2one=None,
         raise TypeError(f"sample! for {type(MCMC).__name__} has no `intercept` keyword")
     if devices is not None:
         return _sample_farm(MCMC, intercept, itemtype == "1pl", cov2one, list(devices))
+    if MCMC.farm is not None:
+        MCMC.farm.close()
+        MCMC.farm = None
     eng = MCMC._engine_for(intercept, itemtype == "1pl", cov2one)
     eng.reset_trace()
     eng.set_state(**MCMC._state_for_engine())
     eng.run(MCMC.Cond.nIter * MCMC.Cond.nChain)
-    MCMC._fill_post(eng)
-    MCMC._update_para(eng)
+    if fill:
+        MCMC._fill_post(eng)
+        MCMC._update_para(eng)
     return MCMC
 
 
@@ -432,13 +447,25 @@ def getLogLikelihood(MCMC: _GibbsBase, P: InputPara) -> float:
     return float(ll)
 
 
-def getDic(MCMC: _GibbsBase) -> OutputDic:
-    """src/GibbsRtIrt.pl.jl:432-458 (and Cross :329-353, Latent :341-365): D̂ = -2 logLik(Post.mean),
-    D̄ = -2 mean(Post.logLike) over ALL iterations (burn-in included, as the reference does)."""
+def getDicHost(MCMC: _GibbsBase) -> OutputDic:
+    """getDic evaluated with numpy on the host from MCMC.Data and MCMC.Post (the test twin of the device path below; needs the data set and
+    Post.mean on the host)."""
     Dhat = -2.0 * getLogLikelihood(MCMC, MCMC.Post.mean)
     Dbar = -2.0 * float(np.mean(MCMC.Post.logLike))
     pD = Dbar - Dhat
     return OutputDic(pD=pD, DIC=Dbar + pD)
+
+
+def getDic(MCMC: _GibbsBase) -> OutputDic:
+    """src/GibbsRtIrt.pl.jl:432-458 (and Cross :329-353, Latent :341-365): D̂ = -2 logLik(Post.mean),
+    D̄ = -2 mean(Post.logLike) over ALL iterations (burn-in included, as the reference does).  Computed by the engine from device-resident
+    state (erm_get_dic / erm_farm_get_dic: the logLike rows, the running sums behind Post.mean and ONE evaluation pass over the resident data
+    set): neither the data set nor an N-wide mean has to be on the host.  Call it after sample!, before the sampler is closed."""
+    src = getattr(MCMC, "farm", None) or MCMC._engine
+    if src is None:
+        raise ValueError("run sample! first (getDic reads the engine's resident state)")
+    d = src.dic()
+    return OutputDic(pD=d["pD"], DIC=d["DIC"])
 
 
 def ess_rhat(x: np.ndarray):
@@ -475,11 +502,12 @@ def ess_rhat(x: np.ndarray):
     return M * n / (-1.0 + 2.0 * total), float(np.sqrt(varp / W))
 
 
-def checkConvergence(MCMC: _GibbsBase) -> dict:
+def checkConvergence(MCMC: _GibbsBase, *, detail=True) -> dict:
     """src/SimTools.jl:419-443: share of the ra / rt / qr columns with ESS > 400 and R-hat < 1.1 after burn-in.  The reference runs
     MCMCChains' `ess_rhat` on the host; here both statistics come from the device-resident traces (erm_get_diagnostics; split-R-hat and
     Geyer's initial-monotone-sequence ESS, not rank-normalised -- MCMCChains' version is not pinned by the reference).  Columns that
-    never move (NaN) are left out of the denominators, as the reference does for qr."""
+    never move (NaN) are left out of the denominators, as the reference does for qr.  detail=False also COUNTS on the device
+    (erm_get_convergence): eight integers cross the boundary instead of the N-wide ess / rhat vectors."""
     eng = MCMC._engine
     if eng is None:
         raise ValueError("run sample! first")
@@ -489,16 +517,21 @@ def checkConvergence(MCMC: _GibbsBase) -> dict:
         if which == _lib.TRACE_RT and MCMC._model == _lib.MODEL_MLIRT:
             continue
         try:
-            ess, rhat = eng.diagnostics(which)
+            if detail:
+                ess, rhat = eng.diagnostics(which)
+                c = (int(np.sum(~np.isnan(ess))), int(np.sum(ess > 400)), int(np.sum(~np.isnan(rhat))), int(np.sum(rhat < 1.1)))
+                out[name] = (ess, rhat)
+            else:
+                c = eng.convergence(which)
         except _lib.ErmError:
             if which != _lib.TRACE_QR:
                 raise
             continue                                    # CrossQr without a resident nu trace
-        out[name] = (ess, rhat)
-        ess_n += int(np.sum(~np.isnan(ess))); rhat_n += int(np.sum(~np.isnan(rhat)))
-        ess_ok += int(np.sum(ess > 400)); rhat_ok += int(np.sum(rhat < 1.1))
-    return dict(ess=100.0 * ess_ok / max(ess_n, 1), rhat=100.0 * rhat_ok / max(rhat_n, 1), essN=f"{ess_ok} / {ess_n}",
-                rhatN=f"{rhat_ok} / {rhat_n}", detail=out)
+        ess_n += c[0]; ess_ok += c[1]; rhat_n += c[2]; rhat_ok += c[3]
+    res = dict(ess=100.0 * ess_ok / max(ess_n, 1), rhat=100.0 * rhat_ok / max(rhat_n, 1), essN=f"{ess_ok} / {ess_n}", rhatN=f"{rhat_ok} / {rhat_n}")
+    if detail:
+        res["detail"] = out
+    return res
 
 
 def coef(MCMC: _GibbsBase) -> dict:

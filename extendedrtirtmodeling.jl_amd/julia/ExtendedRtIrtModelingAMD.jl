@@ -18,7 +18,7 @@ module ExtendedRtIrtModelingAMD
 using LinearAlgebra, Random
 
 export sample!, GibbsMlIrt, GibbsRtIrt, GibbsRtIrtCrossQr, GibbsRtIrtLatentQr, GibbsRtIrtQuantile, GibbsRtIrtNull, GibbsRtIrtCross,
-       GibbsRtIrtLatent, essRhat, simulateData!, libertirt_path!, rcclUniqueId
+       GibbsRtIrtLatent, essRhat, simulateData!, libertirt_path!, rcclUniqueId, getDicDevice, checkConvergenceDevice, setSeed!
 
 const LIB = Ref{String}(get(ENV, "LIBERTIRT", "libertirt.so"))
 libertirt_path!(p::AbstractString) = (LIB[] = String(p))
@@ -42,6 +42,12 @@ const TRACE_RA, TRACE_RT, TRACE_QR, TRACE_LOGLIKE = Int32(0), Int32(1), Int32(2)
 
 lasterr() = unsafe_string(ccall((:erm_last_error, LIB[]), Cstring, ()))
 check(rc::Integer) = rc == 0 ? nothing : error("libertirt: " * lasterr())
+# the struct mirrors above were written against ERM_ABI_VERSION 4 of include/ertirt.h
+const ABI_VERSION = 4
+function checkAbi()
+    v = ccall((:erm_abi_version, LIB[]), Cint, ())
+    v == ABI_VERSION || error("libertirt: the library's struct layout version is $v, this module was written against $ABI_VERSION")
+end
 
 # ---- the reference's containers (src/Base.pl.jl:100-115), reproduced so the module is self-contained when used stand-alone;
 # inside the reference package these definitions are simply dropped in favour of the existing ones.
@@ -125,6 +131,7 @@ function engine!(M::GibbsAMD, intercept::Bool, onepl::Bool, cov2one::Bool; uploa
     cfg = ErmConfig(modelid(M), C.nItem, C.nSubj, C.nFeat, C.nIter, C.nChain, C.nBurnin, intercept, onepl, cov2one, 0, 0, C.qRt,
                     M.seed, M.device, M.precision, 1, 0, 0, 0, 0, 0, 0.0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
+    checkAbi()
     check(ccall((:erm_create, LIB[]), Cint, (Ref{ErmConfig}, Ref{Ptr{Cvoid}}), cfg, h))
     if M.shard !== nothing       # one chain over several devices (include/ertirt.h, erm_set_shard_rccl): collective, before the data
         rank, count, ntot, base, uid = M.shard
@@ -265,6 +272,47 @@ function essRhat(M::GibbsAMD, which::Integer)
     ess, rhat = zeros(w), zeros(w)
     check(ccall((:erm_get_diagnostics, LIB[]), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}), M.handle, which, ess, rhat))
     return ess, rhat
+end
+
+"""
+    getDicDevice(MCMC) -> (Dbar, Dhat, pD, DIC)
+
+`getDic` (src/GibbsRtIrt.pl.jl:432-472, src/GibbsRtIrtCross.pl.jl:330-353, src/GibbsRtIrtLatent.pl.jl:342-365) from device-resident state
+(`erm_get_dic`): D̄ over every recorded logLike row, D̂ from one evaluation pass at `Post.mean` on the device.  Call after `sample!`.
+"""
+function getDicDevice(M::GibbsAMD)
+    M.handle == C_NULL && error("run sample! first")
+    out = zeros(4)
+    check(ccall((:erm_get_dic, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}), M.handle, out))
+    return (Dbar = out[1], Dhat = out[2], pD = out[3], DIC = out[4])
+end
+
+"""
+    checkConvergenceDevice(MCMC) -> (ess, rhat, essN, rhatN)
+
+`checkConvergence` (src/SimTools.jl:419-443) with the ESS / R-hat of every column computed AND counted on the device (`erm_get_convergence`).
+"""
+function checkConvergenceDevice(M::GibbsAMD)
+    M.handle == C_NULL && error("run sample! first")
+    tot = zeros(Int64, 4)
+    for which in (TRACE_RA, TRACE_RT, TRACE_QR)
+        which == TRACE_RT && M isa GibbsMlIrt && continue
+        c = zeros(Int64, 4)
+        check(ccall((:erm_get_convergence, LIB[]), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), M.handle, which, c))
+        tot .+= c
+    end
+    return (ess = 100 * tot[2] / max(tot[1], 1), rhat = 100 * tot[4] / max(tot[3], 1), essN = "$(tot[2]) / $(tot[1])", rhatN = "$(tot[4]) / $(tot[3])")
+end
+
+"""
+    setSeed!(MCMC, seed)
+
+A new seed for the chain's random streams (`erm_set_seed`): one sampler serves every replication of a `runSimulation` condition.
+"""
+function setSeed!(M::GibbsAMD, seed::Integer)
+    M.seed = seed
+    M.handle != C_NULL && check(ccall((:erm_set_seed, LIB[]), Cint, (Ptr{Cvoid}, UInt64), M.handle, UInt64(seed)))
+    return M
 end
 
 """

@@ -13,6 +13,15 @@ from __future__ import annotations
 import numpy as np
 
 SUMMARY_FIELDS = ("theta", "a", "b", "zeta", "lam", "sig2t", "beta", "Sigp", "rho", "nu")
+MAX_CHAINS = 256       # the random streams carry eight bits of the chain id (include/ertirt.h, erm_config.chain_id): chain 256 would replay chain 0
+
+
+def rank_chain_id(rank: int) -> int:
+    """The random stream of the chain a rank runs: its rank, which must fit the eight bits the streams carry (erm_create refuses anything else)."""
+    rank = int(rank)
+    if not 0 <= rank < MAX_CHAINS:
+        raise ValueError(f"rank {rank} cannot be a chain id: independent chains are numbered 0 .. {MAX_CHAINS - 1}")
+    return rank
 
 
 def pack_summary(mean, count: int, loglike_sum: float = 0.0, fields=SUMMARY_FIELDS):

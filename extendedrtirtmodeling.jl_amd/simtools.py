@@ -173,19 +173,68 @@ def _field(obj, name):
     return np.asarray(getattr(obj, _ALIASES.get(name, name)), dtype=np.float64)
 
 
+_STATE_FIELD = {"a": "a", "b": "b", "lam": "lambda_", "sig2t": "sig2t", "rho": "rho", "beta": "beta", "Sigp": "sigp", "theta": "theta", "zeta": "zeta", "nu": "nu"}
+
+
+def _device_generator(funcData, funcGibbs):
+    """True when funcData is one of this module's own generators and it is the one the sampler's device generator restates (erm_simulate_data picks the
+    generator by model: src/SimTools.jl:117-368), so that a replication's data set can be made on the device."""
+    from . import _lib
+    pairs = {setDataMlIrt: (_lib.MODEL_MLIRT,), setDataRtIrt: (_lib.MODEL_RTIRT,), setDataRtIrtNull: (_lib.MODEL_NULL,),
+             setDataRtIrtCross: (_lib.MODEL_CROSS, _lib.MODEL_CROSSQR), setDataRtIrtLatent: (_lib.MODEL_LATENT, _lib.MODEL_LATENTQR)}
+    return funcData in pairs and getattr(funcGibbs, "_model", None) in pairs[funcData]
+
+
 def runSimulation(Cond: SimConditions, truePara: InputPara, *, Para=("a", "b", "λ", "σ²t"), funcData=None, funcGibbs=None, typeName="norm",
-                  seed=4321, **gibbs_opts):
+                  seed=4321, on_device=None, **gibbs_opts):
     """src/SimTools.jl:457-495: Cond.nRep replications of  data <- funcData(Cond, truePara); MCMC <- funcGibbs(Cond; truePara, Data);
     sample!(MCMC);  keeping Post.mean of the parameters in `Para`, the DIC and checkConvergence's summary of every replication.
     funcData / funcGibbs are callables (the reference looks their names up in Main); defaults setDataRtIrt / GibbsRtIrt.
-    Returns {"True": {par: vec}, 1: {par: vec, "Dic": [dic], "Diag": {...}}, ..., nRep: {...}} like the reference's Dict."""
+    Returns {"True": {par: vec}, 1: {par: vec, "Dic": [dic], "Diag": {...}, "Seconds": s}, ..., nRep: {...}} like the reference's Dict.
+
+    on_device (default: whenever funcData is the generator the sampler's model has on the device): the whole study stays on the GPU.  ONE
+    sampler and ONE engine serve all replications of the condition; a replication generates its data set there (erm_simulate_data: no host
+    generation, no upload), re-seeds the chain (erm_set_seed), samples, and returns summaries only -- the requested Post.mean fields
+    (erm_get_mean with only those pointers set), the DIC (erm_get_dic: one evaluation pass at Post.mean on the device) and checkConvergence's
+    eight counters (erm_get_convergence).  Neither the data set, nor a trace, nor (unless `Para` names theta / zeta / nu) anything N-wide
+    crosses the boundary.  on_device=False is the older host path: numpy generation, upload, a fresh engine per replication."""
+    import copy
     import inspect
+    import time
     from . import gibbs
     funcData = funcData or setDataRtIrt
     funcGibbs = funcGibbs or gibbs.GibbsRtIrt
     Run = {"True": {p: _field(truePara, p).reshape(-1, order="F") for p in Para}}
+    if on_device is None:
+        on_device = _device_generator(funcData, funcGibbs)
+    elif on_device and not _device_generator(funcData, funcGibbs):
+        raise ValueError("on_device=True needs funcData to be the generator of funcGibbs' model (setDataRtIrt for GibbsRtIrt, ...)")
+    if on_device:
+        MCMC = funcGibbs(Cond, truePara=truePara, seed=seed + 1, **gibbs_opts)
+        which = sorted({_STATE_FIELD[_ALIASES.get(p, p)] for p in Para})
+        try:
+            for run in range(1, Cond.nRep + 1):
+                t0 = time.perf_counter()
+                MCMC.seed = seed + run
+                MCMC.setInitialValues()                  # the constructor's draw of every replication (src/GibbsRtIrt.pl.jl:100-102)
+                tp = copy.copy(truePara)
+                gibbs.simulateData(MCMC, tp, type=typeName, seed=int(np.random.SeedSequence([seed, run]).generate_state(1, dtype=np.uint64)[0]),
+                                   pull=False, pull_truth=False)
+                MCMC._engine.set_seed(seed + run)
+                gibbs.sample_b(MCMC, fill=False)
+                eng = MCMC._engine
+                m = eng.get_mean(which)
+                Post = {p: np.asarray(m[_STATE_FIELD[_ALIASES.get(p, p)]], dtype=np.float64).reshape(-1) for p in Para}
+                Post["Dic"] = [eng.dic()["DIC"]]
+                Post["Diag"] = gibbs.checkConvergence(MCMC, detail=False) if MCMC.trace == "full" else None
+                Post["Seconds"] = time.perf_counter() - t0
+                Run[run] = Post
+        finally:
+            MCMC.close()
+        return Run
     takes_type = "type" in inspect.signature(funcData).parameters
     for run in range(1, Cond.nRep + 1):
+        t0 = time.perf_counter()
         kw = dict(seed=np.random.SeedSequence([seed, run]))
         if takes_type:
             kw["type"] = typeName
@@ -196,6 +245,7 @@ def runSimulation(Cond: SimConditions, truePara: InputPara, *, Para=("a", "b", "
             Post = {p: _field(MCMC.Post.mean, p).reshape(-1, order="F") for p in Para}
             Post["Dic"] = [gibbs.getDic(MCMC).DIC]
             Post["Diag"] = {k: v for k, v in gibbs.checkConvergence(MCMC).items() if k != "detail"} if MCMC.trace == "full" else None
+            Post["Seconds"] = time.perf_counter() - t0
         finally:
             MCMC.close()
         Run[run] = Post

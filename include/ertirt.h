@@ -41,9 +41,9 @@ enum { ERM_TRACE_RA = 0, ERM_TRACE_RT = 1, ERM_TRACE_QR = 2, ERM_TRACE_LOGLIKE =
  * (intercept, itemtype, cov2one: src/GibbsRtIrt.pl.jl:210,278; src/GibbsRtIrtCross.pl.jl:265; src/GibbsRtIrtLatent.pl.jl:271). */
 typedef struct {
     int32_t model;          /* ERM_MODEL_* */
-    int32_t n_item;         /* Cond.nItem */
+    int32_t n_item;         /* Cond.nItem; 1 .. 896 (the fused sweep kernel keeps per-wave item accumulators in LDS; beyond ~400 items the engine takes the two-kernel schedule) */
     int64_t n_subj;         /* Cond.nSubj */
-    int32_t n_feat;         /* Cond.nFeat (columns of Data.X; ignored by CrossQr) */
+    int32_t n_feat;         /* Cond.nFeat (columns of Data.X; ignored by the Cross family and Null); 0 .. 14 (the structural draws hold the <= 16-column design [1 X theta] in LDS) */
     int32_t n_iter;         /* Cond.nIter */
     int32_t n_chain;        /* Cond.nChain: sweep (m,l) of the reference's interleaved loop is trace row m*nChain+l */
     int32_t n_burnin;       /* Cond.nBurnin (setCond forces round(nIter/2); the host shim does the same) */
@@ -51,7 +51,7 @@ typedef struct {
     int32_t one_pl;         /* itemtype == "1pl" */
     int32_t cov2one;        /* sample!(...; cov2one) */
     int32_t sigp_mode;      /* LatentQr Sigma_p scale: 0 = reference expression src/Draw.pl.jl:594 (the N x N `/` in closed form), 1 = the evidently intended sum r_i^2/(2 k2 nu_i) */
-    int32_t chain_id;       /* selects an independent random stream (one chain per GPU farms use the rank) */
+    int32_t chain_id;       /* selects an independent random stream (one chain per GPU farms use the rank); 0 .. 255 (eight bits of the Philox counter) */
     double  q_rt;           /* Cond.qRt */
     uint64_t seed;
     int32_t device;         /* HIP device ordinal */
@@ -62,14 +62,17 @@ typedef struct {
     int32_t grid_blocks;    /* 0 = auto */
     int32_t profile;        /* 1 = bracket sweep-kernel launches with HIP events for erm_get_timing: two single sweeps before every replayed 32-sweep block of a
                              * long run; every sweep (in replayed 16- / 4-sweep graphs) of a run shorter than 68 sweeps */
-    int32_t flags;          /* ERM_FLAG_* (diagnostics; none changes a result) */
-    double  nu_trace_max_gb; /* GibbsRtIrtCrossQr, ERM_TRACE_FULL: budget in GiB for the per-sweep vec(nu) block of Post.qr (0 = the default, 16) */
+    int32_t flags;          /* ERM_FLAG_* (diagnostics; a schedule flag keeps the launch geometry, so none changes a result); bits outside ERM_FLAG_ALL are refused */
+    double  nu_trace_max_gb; /* GibbsRtIrtCrossQr, ERM_TRACE_FULL: budget in GiB for the per-sweep vec(nu) block of Post.qr (0 = the default, 16; negative or NaN is refused) */
 } erm_config;
 enum {
     ERM_FLAG_NO_FUSE = 1,          /* two kernels per sweep (stand-alone tiny step + row pass) instead of the fused sweep kernel */
     ERM_FLAG_NO_GRAPH = 2,         /* enqueue every sweep instead of replaying the captured 32-sweep hipGraph */
     ERM_FLAG_FARM_FORCE_RCCL = 4,  /* erm_farm_get_mean reduces over RCCL even when all chains share one device (one-rank communicator; tests) */
-    ERM_FLAG_NO_PERSIST = 8        /* small data sets: one launch per sweep instead of ONE persistent launch per erm_run (the statistics cross between its sweeps as tagged packets) */
+    ERM_FLAG_NO_PERSIST = 8,       /* small data sets: one launch per sweep instead of ONE persistent launch per erm_run (the statistics cross between its sweeps as tagged packets) */
+    ERM_FLAG_TEST_PERSIST_TIMEOUT = 16, /* tests: the SECOND persistent erm_run of the engine loses one workgroup's statistics packet and waits 2 ms instead of 1 s, so that
+                                        * the time-out -> restore -> per-sweep replay path of erm_run is exercised (the chain is still the per-sweep chain bit for bit) */
+    ERM_FLAG_ALL = 31
 };
 
 /* Mirrors InputPara (src/Base.pl.jl:100-115).  NULL members are skipped.  Shapes:
@@ -89,6 +92,9 @@ typedef struct {
     int32_t lanes_per_row, block_threads, grid_blocks, lds_bytes;
     int32_t cu_count;
     int32_t persistent;     /* 1 = this engine runs erm_run as ONE persistent launch (small data sets; ERM_FLAG_NO_PERSIST turns it off) */
+    int32_t persist_fallbacks; /* persistent launches that timed out waiting for a workgroup that never became resident (another process holds compute units): the
+                             * erm_run restored the state it had saved, replayed the call on the per-sweep schedule and the engine stays there (persistent = 0) */
+    int32_t reserved_;
 } erm_timing;
 
 /* Replaces the Gibbs* constructors' allocation of Post and Para (src/GibbsRtIrt.pl.jl:94-104,134-144). */
@@ -116,6 +122,9 @@ int erm_get_state(erm_handle h, erm_state* st);
 /* The body of `for m in 1:nIter, l in 1:nChain` (src/GibbsRtIrt.pl.jl:221-246, 289-324; Cross :276-302; Latent :282-314):
  * runs `nsweeps` sweeps continuing from the current state; sweeps fill trace rows in order. */
 int erm_run(erm_handle h, int64_t nsweeps);
+/* A new seed for the chain's random streams (a simulation study re-uses ONE engine for all replications of a condition: src/SimTools.jl:457-495 constructs a
+ * fresh sampler per replication, which draws from Julia's global stream).  Takes effect with the next erm_run. */
+int erm_set_seed(erm_handle h, uint64_t seed);
 int64_t erm_rows_done(erm_handle h);
 int erm_reset_trace(erm_handle h);   /* forget recorded rows and running means (state is kept) */
 
@@ -137,6 +146,15 @@ int64_t erm_post_count(erm_handle h);   /* number of rows that entered the means
  * sample size by Geyer's initial monotone sequence over the 2*nChain split chains (the non-rank-normalised estimator); NaN for a column
  * that never moves.  Needs ERM_TRACE_FULL and a completed run. */
 int erm_get_diagnostics(erm_handle h, int which, double* ess, double* rhat);
+/* checkConvergence's summary itself (src/SimTools.jl:427-437) without the N-wide vectors: counts4 = { columns with a defined ESS, of those ESS > 400, columns with a
+ * defined R-hat, of those R-hat < 1.1 } for trace `which`, counted on the device. */
+int erm_get_convergence(erm_handle h, int which, int64_t* counts4);
+
+/* getDic (src/GibbsRtIrt.pl.jl:432-472, src/GibbsRtIrtCross.pl.jl:330-353, src/GibbsRtIrtLatent.pl.jl:342-365) from device-resident state:
+ * out = { Dbar, Dhat, pD, DIC } with Dbar = -2 mean(Post.logLike) over ALL recorded rows (burn-in included, as the reference does), Dhat = -2 logLik(Post.mean) from
+ * ONE evaluation pass over the resident data set at the running means (theta, zeta, nu sums and the post-burn-in item-level trace rows; nothing N-wide crosses
+ * the boundary), pD = Dbar - Dhat, DIC = Dbar + pD.  Needs a run with post-burn-in rows. */
+int erm_get_dic(erm_handle h, double* out4);
 
 int erm_get_timing(erm_handle h, erm_timing* out);
 /* Subject sharding of ONE chain over several devices (second bullet).  The reference has no counterpart: its
@@ -187,6 +205,8 @@ int erm_farm_run(erm_farm_handle f, int64_t nsweeps);                           
 int erm_farm_reset_trace(erm_farm_handle f);
 int erm_farm_get_trace(erm_farm_handle f, int which, double* out);
 int erm_farm_get_mean(erm_farm_handle f, erm_state* out);
+int erm_farm_get_dic(erm_farm_handle f, double* out4);     /* as erm_get_dic: Dbar over the rows of all chains, Dhat at the joint Post.mean (the same reduction as erm_farm_get_mean, evaluated on the first device) */
+int erm_farm_set_seed(erm_farm_handle f, uint64_t seed);
 int64_t erm_farm_post_count(erm_farm_handle f);
 int erm_farm_used_rccl(erm_farm_handle f);                  /* 1 if the last erm_farm_get_mean reduced over RCCL */
 /* What a multi-GPU benchmark of the farm reports: wall-clock of the last erm_farm_run (all chains, host side), the device time of each chain's
@@ -201,6 +221,10 @@ int erm_farm_get_timing(erm_farm_handle f, erm_farm_timing* out, double* run_ms)
 
 const char* erm_last_error(void);
 const char* erm_version(void);
+/* Layout version of the structs above (erm_config, erm_timing, ...): a binder compares it with the ERM_ABI_VERSION it was written against before the first
+ * erm_create.  4: erm_timing grew by persist_fallbacks; erm_config.flags refuses unknown bits. */
+#define ERM_ABI_VERSION 4
+int erm_abi_version(void);
 
 /* Diagnostics: run a device sampler on n independent streams (stream k = (seed, site, i=k, sweep)); used by the parity
  * tests to compare the device restatement of each sampler with the oracle.  which: 0 uniform, 1 normal, 2 expo,
@@ -209,6 +233,10 @@ const char* erm_version(void);
  * 11-14 the fp64 cell path's log(par0), exp(-par0), sqrt(par0), par0 / par1; 15 its table-driven log(par0), 16 cos(2 pi par0), 17 its form of the QR weight (par0 = |residual|, par1 = parB at unit scale: the same variate as 8). */
 int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32_t site, uint32_t sweep, int64_t n,
                      const double* par0, const double* par1, double* out);
+
+/* n draws of the 2 x 2 InverseWishart(nu, Psi) of drawSubjCovariance (src/Draw.pl.jl:499-515) through the device code the structural step runs (Bartlett factor of
+ * the Wishart on Psi^-1, then the inverse): out[4 k .. 4 k + 3] = vec(Sigma) of draw k, which uses stream (seed, site SIGP, i = k, sweep).  psi = vec(Psi). */
+int erm_debug_invwishart(int device, uint64_t seed, uint32_t sweep, int64_t n, double nu, const double* psi4, double* out);
 
 /* n draws of the generalized inverse Gaussian GIG(p, a, b) (density ~ x^(p-1) exp(-(a x + b/x)/2); the distribution type of
  * src/GenInvGaussian.jl:17-30, whose sampler :76-106 is dead code in the reference) by Devroye's (2014) sampler, fp64; element k uses

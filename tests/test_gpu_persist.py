@@ -90,3 +90,44 @@ def test_persistent_runs_are_reproducible_over_long_chains():
         for _ in range(6):
             got = pu.run_device(model, Y, logT, X, init, 300, precision="f64", trace_full=False)
             assert np.array_equal(got["item"], ref["item"]) and np.array_equal(got["ll"], ref["ll"]), (model, N, J)
+
+
+@pytest.mark.parametrize("model,precision", [("rtirt", "f64"), ("mlirt", "f32"), ("latentqr", "f64")])
+def test_a_persistent_launch_that_times_out_is_replayed_per_sweep(model, precision):
+    """ERM_FLAG_TEST_PERSIST_TIMEOUT makes workgroup 1 of the engine's second persistent erm_run lose its statistics row and shortens the wait to 2 ms:
+    the launch times out, every workgroup leaves it, and erm_run restores the state it saved, drops the persistent schedule and replays the call
+    one launch per sweep.  The call SUCCEEDS, erm_timing says what happened, and the chain is the chain of an undisturbed engine bit for bit --
+    also across a run that continues it, and with post-burn-in sums (Post.mean) that were saved and restored."""
+    Y, logT, X, init, _ = pu.make_problem(model, 1000, 15)
+    good = pu.run_device(model, Y, logT, X, init, 40, precision=precision, n_burnin=5)
+    assert good["engine"].timing()["persistent"] == 1 and good["engine"].timing()["persist_fallbacks"] == 0
+    eng = L.Engine(model=pu.MODELS[model], n_item=15, n_subj=1000, n_feat=3, n_iter=40, n_chain=1, n_burnin=5, cov2one=int(model != "latentqr"), q_rt=0.85, seed=1234,
+                   precision={"f32": 0, "f64": 1}[precision], trace_mode=1, flags=L.FLAG_TEST_PERSIST_TIMEOUT)
+    assert eng.timing()["persistent"] == 1
+    eng.set_data(Y, logT, X)
+    eng.set_state(**{("lambda_" if k == "lam" else k): v for k, v in init.items()})
+    eng.run(8)                                    # a persistent run that succeeds: post-burn-in rows and sums exist before the failing call
+    tm = eng.timing()
+    assert tm["persistent"] == 1 and tm["persist_fallbacks"] == 0
+    eng.run(20)                                   # the engine's second persistent run loses a packet: time-out, restore, per-sweep replay
+    tm = eng.timing()
+    assert tm["persistent"] == 0 and tm["persist_fallbacks"] == 1
+    eng.run(12)
+    assert eng.timing()["persist_fallbacks"] == 1
+    assert np.array_equal(eng.item_trace(), good["item"]) and np.array_equal(eng.trace(L.TRACE_RA), good["ra"]) and np.array_equal(eng.trace(L.TRACE_LOGLIKE), good["ll"])
+    gm, em = good["engine"].get_mean(), eng.get_mean()
+    for k, v in gm.items():
+        assert v is None or np.array_equal(v, em[k]), k
+
+
+def test_schedule_flags_keep_the_default_geometry():
+    """ERM_FLAG_NO_PERSIST changes the schedule, not the launch geometry: with nothing pinned the per-sweep engine runs the persistent plan's workgroups
+    (erm_geometry.hpp), sums its statistics in the same association and draws the same chain bit for bit."""
+    for model, N, J in (("rtirt", 1000, 15), ("mlirt", 300, 20)):
+        Y, logT, X, init, _ = pu.make_problem(model, N, J)
+        per = pu.run_device(model, Y, logT, X, init, 30, precision="f64")
+        ref = pu.run_device(model, Y, logT, X, init, 30, precision="f64", flags=L.FLAG_NO_PERSIST)
+        tp, tr = per["engine"].timing(), ref["engine"].timing()
+        assert (tp["persistent"], tr["persistent"]) == (1, 0)
+        assert (tp["block_threads"], tp["grid_blocks"]) == (tr["block_threads"], tr["grid_blocks"])
+        assert _same(per, ref)

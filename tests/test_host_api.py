@@ -183,3 +183,32 @@ def test_julia_shim_mirrors_the_header_structs():
     called = set(re.findall(r"ccall\(\(:(erm_\w+)", jl))
     declared = set(re.findall(r"\b(erm_[a-z_]+)\s*\(", hdr))
     assert called and called <= declared, called - declared
+
+
+def test_erm_create_refuses_what_it_cannot_honour_before_touching_a_device():
+    """chain ids beyond the eight bits the random streams carry (chain 256 would silently replay chain 0), unknown flag bits (a caller built against
+    another header), a negative / NaN nu-trace budget: ERM_ERR_ARG with a message, checked before any HIP call (so this runs without a GPU).  The struct
+    layout version is exported for binders."""
+    import ctypes as C
+    L = pkg._lib
+    lib = L.load()
+    assert lib.erm_abi_version() == L.ABI_VERSION == int(re.search(r"#define ERM_ABI_VERSION (\d+)", open(os.path.join(pu.ROOT, "include", "ertirt.h")).read()).group(1))
+    assert b"0.4" in lib.erm_version()
+
+    def create(**kw):
+        cfg = L.erm_config(model=1, n_item=5, n_subj=50, n_feat=2, n_iter=4, n_chain=1, n_burnin=2, q_rt=0.5, seed=1, precision=1, trace_mode=1)
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.erm_create(C.byref(cfg), C.byref(h))
+        return rc, lib.erm_last_error().decode()
+
+    for kw, what in ((dict(chain_id=256), "chain_id"), (dict(chain_id=-1), "chain_id"), (dict(flags=64), "flags"), (dict(flags=1 << 20), "flags"),
+                     (dict(nu_trace_max_gb=-1.0), "nu_trace_max_gb"), (dict(nu_trace_max_gb=float("nan")), "nu_trace_max_gb"), (dict(trace_mode=7), "trace_mode")):
+        rc, msg = create(**kw)
+        assert rc == -1 and what in msg, (kw, rc, msg)
+    with pytest.raises(ValueError, match="chain_id"):
+        pkg.GibbsRtIrt(pkg.setCond(nSubj=10, nItem=3, nFeat=1, nIter=4, nChain=1), chain_id=300)
+    with pytest.raises(ValueError):
+        pkg.parallel.rank_chain_id(256)
+    assert pkg.parallel.rank_chain_id(7) == 7
