@@ -46,6 +46,22 @@ HBM_PEAK_GBS = 8000.0                                                     # MI35
 NAMES = {'mlirt': 'MlIrt', 'rtirt': 'RtIrt', 'latentqr': 'RtIrtLatentQr', 'crossqr': 'RtIrtCrossQr', 'null': 'RtIrtNull', 'cross': 'RtIrtCross', 'latent': 'RtIrtLatent'}
 
 
+def baseline_config(model, N, J, chains=1):
+    """Which entry of BASELINE.json's `configs` a workload is (the label in `config.workload`): '' for a workload BASELINE.json does not list."""
+    key = (model, N, J)
+    if key == ("mlirt", 1000, 15):
+        return "BASELINE.json configs[0]"
+    if key == ("mlirt", 100000, 50):
+        return "BASELINE.json configs[1]"
+    if key == ("rtirt", 100000, 50):
+        return "BASELINE.json configs[2]" + (" per GPU" if chains > 1 else "")
+    if key == ("latentqr", 100000, 50):
+        return "BASELINE.json configs[3]"
+    if key == ("rtirt", 500000, 100):
+        return "BASELINE.json configs[4]" + ("" if chains == 8 else f": its per-GPU load, {chains} of 8 chains")
+    return "not a BASELINE.json configuration"
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +87,7 @@ def parse_args(argv=None):
     ap.add_argument("--shard", action="store_true", help="NOT the headline: ONE chain of --nsubj subjects sharded over the ranks (strong scaling; "
                                                         "one all-gather of a statistics row per row pass, SURVEY.md 8(e))")
     ap.add_argument("--multiprocess", action="store_true", help="N > 1: one process per GPU over torch.distributed instead of the library's in-process chain farm")
+    ap.add_argument("--no-self-check", action="store_true", help="N > 1: skip the farm's self-validation (communicator size, farm mean = separately run engines, per-chain time)")
     ap.add_argument("--no-cold", action="store_true", help="skip the extra cold measurement (the same W + K steps from an idle device, before the clock warm-up)")
     return ap.parse_args(argv)
 
@@ -381,14 +398,79 @@ def roofline(model, N, J, n_loc, precision, tm):
            "frac_of_achievable": ach / 6300.0, "achievable_peak": 6300.0, "launch_us": per_launch_s * 1e6, "event_overhead_us": tm["event_overhead_ms"] * 1e3,
            "algorithmic_bytes_per_cell_update": ALGO_BYTES[precision][model], "algorithmic_bytes_per_launch": algo, "launches_timed": int(tm["pass_launches"]),
            "launch_us_source": "HIP events on the engine's stream around sweep-kernel launches of the timed region (live)"}
+    # what the same launch time is worth against other yardsticks: the fp32 layout SURVEY.md 8(d) quotes first (13 B per cell-update for GibbsRtIrt) when the engine
+    # stores fp64 (25 B: the representation this engine chose, not a property of the algorithm), and where the bytes come from at this size
+    ws = float(n_loc) * J * {"mlirt": 2, "rtirt": 3, "latentqr": 3, "null": 3, "latent": 3, "cross": 3, "crossqr": 4}[model] * (8 if precision == "f64" else 4)
+    out["working_set_bytes"] = ws
+    out["infinity_cache_resident"] = bool(ws <= 256 * 2 ** 20)
+    if precision == "f64":
+        out["frac_fp32_layout"] = ALGO_BYTES["f32"][model] * float(n_loc) * J / launches_per_sweep / per_launch_s / 1e9 / HBM_PEAK_GBS
+    out["yardstick_note"] = ("frac prices the engine's own representation (fp64 engine: 25 B per cell-update; frac_fp32_layout prices the same launch at SURVEY.md 8(d)'s fp32 figure). "
+                             + ("The matrices of this workload fit the 256 MiB Infinity Cache, so most of these bytes never reach HBM: the fraction of the HBM peak is nominal."
+                                if ws <= 256 * 2 ** 20 else "The matrices of this workload exceed the 256 MiB Infinity Cache: the bytes come from HBM."))
     if off is not None and off.get("valu") is not None:
         out["valu"] = dict(off["valu"], source="offline rocprofv3 SQ counters (profiles/), not measured in this run")
         # what actually limits the kernel: VALU issue in its Polya-Gamma and column phases (profiles/round3_budget_*.md itemises it stage by stage)
         out["bound_actual"] = "valu"
         out["valu_issue_frac"] = off["valu"].get("valu_busy_frac")
+        if off["valu"].get("valu_busy_frac_weighted") is not None:      # the same busy fraction with every instruction class at its MEASURED issue cost (profiles/round4_valu_issue_rates.txt)
+            out["valu_issue_frac_class_weighted"] = off["valu"]["valu_busy_frac_weighted"]
         out["bound_note"] = ("nominally HBM-bound (SURVEY.md 8(d)); measured: the VALUs are busy for valu_issue_frac of the kernel's cycles (offline SQ counters), the rest is the "
                              "latency of its serial head / tail; HBM-side traffic is far from the 8 TB/s peak")
     return out
+
+
+def farm_self_check(pkg, L, devices, rehearse, prec, headline_per_chain_ms, args, model, N, J, F, data):
+    """Makes a multi-GPU run validate itself: (1) the library's RCCL communicator spans the farm's distinct devices; (2) the farm's
+    Post.mean is the count-weighted mean of the same chains run as SEPARATE engines (one per device, chain_id = l) to 1e-12 -- the comparison
+    tests/test_gpu_farm.py makes on one device; (3) every chain's device time per sweep is within 10 % of a single engine's on device 0 (no chain is slowed down
+    by its neighbours: the farm's chains never communicate while sampling).  Returns a dict with `ok`."""
+    import numpy as np
+    n_dev = len(devices)
+    Nv, Jv, Fv, rows, burn = 20000, 50, F, 24, 8
+    Yv, lv, Xv = make_data(pkg, model, Nv, Jv, Fv, seed=4321)
+    kw = dict(model=getattr(L, "MODEL_" + model.upper()), n_item=Jv, n_subj=Nv, n_feat=Fv if Xv is not None else 0, n_iter=rows, n_chain=1, n_burnin=burn,
+              cov2one=int(model not in ("latentqr", "latent")), q_rt=0.85, seed=1234, precision=L.PREC_F32 if prec == "f32" else L.PREC_F64, trace_mode=L.TRACE_SUMMARY)
+    farm = L.Farm(devices, flags=L.FLAG_FARM_FORCE_RCCL if rehearse else 0, **kw)
+    farm.set_data(Yv, lv, Xv)
+    states = [{("lambda_" if k == "lam" else k): v for k, v in init_state(model, Nv, Jv, Fv, l).items()} for l in range(n_dev)]
+    for l in range(n_dev):
+        farm.set_state(l, **states[l])
+    farm.run(rows)
+    fm = farm.get_mean()
+    ft = farm.timing()
+    tot = farm.post_count
+    del farm
+    acc, cnt = None, 0
+    for l in range(n_dev):
+        eng = L.Engine(chain_id=l, device=devices[l], **kw)
+        eng.set_data(Yv, lv, Xv)
+        eng.set_state(**states[l])
+        eng.run(rows)
+        m, c = eng.get_mean(), eng.post_count
+        vec = np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1) for k, v in sorted(m.items()) if v is not None])
+        acc = vec * c if acc is None else acc + vec * c
+        cnt += c
+        del eng
+    want = acc / cnt
+    got = np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1) for k, v in sorted(fm.items()) if v is not None])
+    err = float(np.max(np.abs(got - want) / (1.0 + np.abs(want))))
+    chk = {"rccl_ranks": int(ft["rccl_ranks"]), "rccl_ranks_expected": 1 if rehearse else len(set(devices)), "farm_mean_vs_separate_engines_max_rel_err": err, "post_rows": int(tot),
+           "post_rows_expected": int(cnt)}
+    ok = chk["rccl_ranks"] == chk["rccl_ranks_expected"] and err <= 1e-12 and tot == cnt
+    # (3) a single engine on device 0 on the headline workload, same steps and warm-up, device time per sweep
+    if not rehearse and headline_per_chain_ms:
+        a1 = argparse.Namespace(**vars(args))
+        a1.no_cold, a1.clock_warmup_ms = True, min(args.clock_warmup_ms, 100.0)
+        import torch
+        dt1, tm1, eng1, _ = measure(pkg, None, torch, None, a1, model, N, J, F, prec, data, init_state(model, N, J, F, 0), 0, 1, devices[0], False, False, args.trace)
+        del eng1
+        single = tm1["run_ms"] / args.steps
+        worst = max(abs(v / single - 1.0) for v in headline_per_chain_ms)
+        chk.update(single_engine_device_ms_per_step=single, per_chain_device_ms_per_step=[float(v) for v in headline_per_chain_ms], worst_relative_deviation=worst)
+        ok = ok and worst <= 0.10
+    chk["ok"] = bool(ok)
+    return chk
 
 
 def main_farm(args, world_env):
@@ -423,6 +505,7 @@ def main_farm(args, world_env):
             dist.destroy_process_group()
         return
     driver = rank == 0
+    rc = 0
     pkg = L = None
     data = None
     model, N, J, F = args.model, args.nsubj, args.nitem, args.nfeat
@@ -479,7 +562,7 @@ def main_farm(args, world_env):
             "metric": "Gibbs cell-updates/s (nSubj x nItem x sweeps/s)", "value": cells * args.steps * n_dev / dt, "unit": "cell-updates/s",
             "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
-            "config": {"workload": f"Gibbs{NAMES[model]} nSubj={N} nItem={J} nFeat={F} nChain={n_dev}, one chain per GPU (BASELINE.json configs[2] per GPU)",
+            "config": {"workload": f"Gibbs{NAMES[model]} nSubj={N} nItem={J} nFeat={F} nChain={n_dev}, one chain per GPU ({baseline_config(model, N, J, n_dev)})",
                        "path": "erm_farm_create / set_data / set_state / run / get_mean (the C-ABI chain farm: one process, one host thread per chain inside the library)",
                        "chains": n_dev, "devices": devices, "subject_shards": 1, "trace": args.trace, "lanes_per_row": etm["lanes_per_row"], "block_threads": etm["block_threads"],
                        "grid_blocks": etm["grid_blocks"], "lds_bytes": etm["lds_bytes"], "ranks": world,
@@ -501,9 +584,19 @@ def main_farm(args, world_env):
             out["fp32"] = fp32
         if cfg4 is not None:
             out["configs4_value"], out["configs4_ms_per_step"], out["configs4"] = cfg4["value"], cfg4["ms_per_step"], cfg4
+        if not args.no_self_check:
+            out["self_check"] = farm_self_check(pkg, L, devices, rehearse, prec, out["per_chain_device_ms_per_step"], args, model, N, J, F, data)
+            rc = 0 if out["self_check"]["ok"] else 3
         out_line.emit(json.dumps(out))
     if dist is not None:
+        # every rank leaves with the driver's verdict (a failed self-check must fail the whole launch)
+        t = torch.tensor([float(rc)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rc = int(t.item())
         dist.destroy_process_group()
+    if rc:
+        print("bench.py: the multi-GPU self-check failed (see self_check in the JSON line)", file=sys.stderr)
+        sys.exit(rc)
 
 
 def main():
@@ -620,7 +713,7 @@ def main():
             "metric": "Gibbs cell-updates/s (nSubj x nItem x sweeps/s)", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
-            "config": {"workload": f"Gibbs{NAMES[model]} nSubj={N} nItem={J} nFeat={F} " + (f"ONE chain, subjects sharded over {world} devices" if shard else "nChain=1 per GPU (BASELINE.json configs[2])"),
+            "config": {"workload": f"Gibbs{NAMES[model]} nSubj={N} nItem={J} nFeat={F} " + (f"ONE chain, subjects sharded over {world} devices (not a BASELINE.json configuration)" if shard else f"nChain=1 per GPU ({baseline_config(model, N, J, world)})"),
                        "chains": 1 if shard else world, "subject_shards": world if shard else 1, "shard_exchange": (("callback" if rehearse else args.shard_exchange) if shard else None), "trace": args.trace, "lanes_per_row": tm["lanes_per_row"], "block_threads": tm["block_threads"],
                        "grid_blocks": tm["grid_blocks"], "lds_bytes": tm["lds_bytes"], "ranks": world, "collective_backend": backend,
                        "rccl_ranks": world if backend == "nccl" else 0},

@@ -731,6 +731,7 @@ template <typename real> struct Engine : EngineBase {
         if (sharded() || !has_stats_state()) stats_valid = false;
         Ctl c{};
         c.sweep = sweeps_total; c.row = (uint32_t)rows_done; c.burn_rows = (uint32_t)((int64_t)cfg.n_burnin * cfg.n_chain); c.err = 0;
+        c.first = 1u;                                // no sweep of this call has been drawn yet: the first one writes trace row rows_done itself
         if (cur == 1) {      // every run starts from buffer 0 so that a captured graph always replays with the buffer parity it was built with
             HIPCHK(hipMemcpyAsync(dParB[0].p, dParB[1].p, dParB[0].bytes, hipMemcpyDeviceToDevice, stream));
             if (stats_valid) HIPCHK(hipMemcpyAsync(dGslab0B[0].p, dGslab0B[1].p, dGslab0B[0].bytes, hipMemcpyDeviceToDevice, stream));
