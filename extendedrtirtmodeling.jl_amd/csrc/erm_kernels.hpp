@@ -138,6 +138,16 @@ __device__ __forceinline__ float  log1pexp_r(float x)  { return fmaxf(x, 0.f) + 
 __device__ __forceinline__ double log1pexp_r(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
 constexpr double LOG_2PI = 1.8378770664093454836;
+// Response-time log-likelihood of the single-pass models from SUFFICIENT STATISTICS instead of per cell (round 4).  With c = logT - column mean,
+//   sum_i (c_ij + zeta_i - lc_j)^2 = csq_j + 2 G_j + zz - 2 lc_j sz + N lc_j^2      (lc_j = lambda_j - mean_j, G_j = sum_i c_ij zeta_i, sz = sum zeta, zz = sum zeta^2),
+// so  LL_rt = -1/2 sum_j [ N (log 2 pi + log sig2t_j) + (csq_j + N lc_j^2) / sig2t_j ]                  (constant in the subjects: the tiny step, par derived[1])
+//             - sum_j G_j / sig2t_j - zz/2 sum_j 1/sig2t_j + sz sum_j lc_j / sig2t_j                     (linear in the statistics: every workgroup, from its own sums)
+// -- statistics the column phase accumulates anyway for the lambda / sig2t draws (tiny_items forms the same expansion).  The column phase loses the residual,
+// its square and the per-item constants of every cell (it is VALU-issue-bound), the head the logarithm of sig2t per item.  Same log-likelihood to ~1e-14.
+#ifndef ERM_RTLL_STATS
+#define ERM_RTLL_STATS 1
+#endif
+template <int MODEL, int PHASE> constexpr bool rtll_stats() { return ERM_RTLL_STATS != 0 && PHASE == 0 && (fam_rt(MODEL) || fam_lq(MODEL)); }
 constexpr int KB = 4;     // items per lane whose loads are in flight together in the row-sum phase
 
 // Stage-timing / counting diagnostics (early returns that leave GARBAGE results, PG attempt counters) exist only in a library built with
@@ -579,6 +589,18 @@ __device__ __forceinline__ void tiny_struct(const TinyArgs& T, double* par, cons
         t = bfly_sum(t, 1, 64);
         if (lane == 0) par[par_off_derived(J)] = t;
     }
+    if constexpr (rtll_stats<MODEL, 0>() && STEP == 0) {
+        // the part of this sweep's response-time log-likelihood that does not depend on the subjects (see ERM_RTLL_STATS): derived[1]
+        // (explicit fma everywhere in this statistic: every instantiation of the kernels must form the same bits, whatever the compiler would contract)
+        double cc = 0.0;
+        for (int jj = lane; jj < J; jj += 64) {
+            const double lc = par[2 * J + jj] - cm[jj];
+            cc = fma(Nd, LOG_2PI + q_log(par[3 * J + jj]), cc);
+            cc = fma(part[jj], fma(Nd * lc, lc, csq[jj]), cc);
+        }
+        cc = bfly_sum(cc, 1, 64);
+        if (lane == 0) par[par_off_derived(J) + 1] = -0.5 * cc;
+    }
     // =========================================================== Sigma_p_t | beta_t (thread 0; its random numbers were pre-drawn above)
     if (lane == 0 && STEP == 0 && MODEL != MLIRT) {
         double S[4] = { 1.0, 0.0, 0.0, 1.0 };
@@ -906,7 +928,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         sweep = c_sweep + 1u;
         ERM_DIAG_STOP(A, 30);
         trow = k_first ? prev_row : prev_row + 1u;
-        if (writer && tid == 0 && !k_first && T.tr_ll) T.tr_ll[prev_row] = st0[NS0 - 1];    // log-likelihood of the sweep the last pass completed
+        // log-likelihood of the sweep the last pass completed (+ the subject-free part its tiny step left in the parameter block: ERM_RTLL_STATS)
+        if (writer && tid == 0 && !k_first && T.tr_ll) T.tr_ll[prev_row] = st0[NS0 - 1] + (rtll_stats<MODEL, PHASE>() ? lp[par_off_derived(J) + 1] : 0.0);
         // item draws now; the structural chain (beta_t -> Sigma_p_t, ~7 us of dependent fp64 work on one wave) runs on wave 0 AFTER the
         // staging barrier below, concurrently with the other waves' row sums, which do not need it (see `sh_ready`)
         // wave 0 starts the pre-barrier part of the structural chain at once (it is the longest strand of the head and needs nothing of
@@ -932,7 +955,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
             }
             for (int j = tid - ioff - rt_off; tid >= ioff + rt_off && j < J; j += jstep) {
                 const double lam = lp[2 * J + j], sg = lp[3 * J + j];
-                sh_lamc[j] = (real)(lam - lcst[cst_off_m(J) + j]); sh_isig[j] = (real)(1.0 / sg); sh_lsig[j] = (real)log(sg);
+                sh_lamc[j] = (real)(lam - lcst[cst_off_m(J) + j]); sh_isig[j] = (real)(1.0 / sg);
+                if constexpr (!rtll_stats<MODEL, PHASE>()) sh_lsig[j] = (real)log(sg);
             }
             if (tid == 0) { *reinterpret_cast<int*>(sh_struct + 5) = 0; *reinterpret_cast<unsigned int*>(sh_struct + 7) = 0u; }       // sh_ready, row-group counter
             for (int e = tid; e < nWaves * NG; e += nthr) sh_gacc[e] = 0.0;
@@ -1484,6 +1508,17 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
             }
             accg = bfly_sum(accg, 1, 64);
             if (tl == 0) sh_gacc[g] = accg;          // wave 0's slot of the per-wave table summed by the epilogue (the other waves' stay 0)
+            if constexpr (rtll_stats<MODEL, PHASE>()) {
+                // ERM_RTLL_STATS: this workgroup's share of the response-time log-likelihood that is linear in sum zeta and sum zeta^2
+                const int g_sz = fam_rt(MODEL) ? p : 2 * p + 5, g_zz = fam_rt(MODEL) ? 2 * p + 2 : 2 * p + 6;
+                if (A.mode == 1 && g == g_sz) {
+                    double sl = 0.0;
+                    for (int jj = tl; jj < J; jj += 64) sl = fma((double)sh_lamc[jj], (double)sh_isig[jj], sl);
+                    sl = bfly_sum(sl, 1, 64);
+                    if (tl == 0) ll = fma(accg, sl, ll);
+                }
+                if (A.mode == 1 && g == g_zz && tl == 0) ll = fma(-0.5 * accg, sh_struct[4], ll);
+            }
         }
     }
 
@@ -1508,7 +1543,10 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 const bool jv = j0 < J;
                 const int jc = jv ? j0 : 0;
                 const double a0 = sh_a[jc], a1 = sh_a[jc + 1], b0 = sh_b[jc], b1 = sh_b[jc + 1];
-                const double lamc0 = sh_lamc[jc], lamc1 = sh_lamc[jc + 1], isig0 = sh_isig[jc], isig1 = sh_isig[jc + 1], lsig0 = sh_lsig[jc], lsig1 = sh_lsig[jc + 1];
+                constexpr bool RTLL = rtll_stats<MODEL, PHASE>();      // the response-time log-likelihood comes from the statistics: no residual per cell
+                [[maybe_unused]] const double lamc0 = RTLL ? 0.0 : (double)sh_lamc[jc], lamc1 = RTLL ? 0.0 : (double)sh_lamc[jc + 1];
+                [[maybe_unused]] const double isig0 = sh_isig[jc], isig1 = sh_isig[jc + 1];
+                [[maybe_unused]] const double lsig0 = RTLL ? 0.0 : (double)sh_lsig[jc], lsig1 = RTLL ? 0.0 : (double)sh_lsig[jc + 1];
                 double S0[NSTAT], S1[NSTAT];
 #pragma unroll
                 for (int q = 0; q < NSTAT; ++q) { S0[q] = 0.0; S1[q] = 0.0; }
@@ -1547,7 +1585,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                                 const double sgn = y ? -eta : eta;                  // y eta - max(eta, 0) = -max(sgn, 0)
                                 lmax += sgn > 0.0 ? sgn : 0.0;
                                 bprod *= 1.0 + fm::exp_neg(fabs(eta));
-                                if (fam_rt(MODEL) || fam_lq(MODEL)) {
+                                if constexpr (!RTLL && (fam_rt(MODEL) || fam_lq(MODEL))) {
                                     const double er = c + ze - lamc;
                                     rtq = fma(er * er, isig, rtq);
                                 }
@@ -1563,13 +1601,14 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 double llc = 0.0;
                 if (A.mode == 1) {
                     llc = -(lmax + fm::log(bprod, logtab));
-                    if (fam_rt(MODEL) || fam_lq(MODEL)) llc -= 0.5 * (rtq + (double)ncells * (2.0 * LOG_2PI + lsig0 + lsig1));
+                    if constexpr (!RTLL && (fam_rt(MODEL) || fam_lq(MODEL))) llc -= 0.5 * (rtq + (double)ncells * (2.0 * LOG_2PI + lsig0 + lsig1));
                 }
 #pragma unroll
                 for (int q = 0; q < NSTAT; ++q) { S0[q] += __shfl_xor(S0[q], 32, 64); S1[q] += __shfl_xor(S1[q], 32, 64); }
                 if (jv && half == 0) {
 #pragma unroll
                     for (int q = 0; q < NSTAT; ++q) { acc[q * J + j0] = S0[q]; acc[q * J + j0 + 1] = S1[q]; }
+                    if constexpr (RTLL) { if (A.mode == 1) llc = fma(-isig1, S1[4], fma(-isig0, S0[4], llc)); }      // - sum_j G_j / sig2t_j of this wave's subjects
                 }
                 ll += llc;
             }
@@ -1588,8 +1627,10 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 const bool jv = j0 < J;
                 const int jc = jv ? j0 : 0;
                 const float a0 = sh_a[jc], a1 = sh_a[jc + 1], b0 = sh_b[jc], b1 = sh_b[jc + 1];
-                const float lamc0 = sh_lamc[jc], lamc1 = sh_lamc[jc + 1], isig0 = sh_isig[jc], isig1 = sh_isig[jc + 1];
-                const float lconst = 2.0f * (float)LOG_2PI + sh_lsig[jc] + sh_lsig[jc + 1];
+                constexpr bool RTLL = rtll_stats<MODEL, PHASE>();
+                [[maybe_unused]] const float lamc0 = RTLL ? 0.0f : (float)sh_lamc[jc], lamc1 = RTLL ? 0.0f : (float)sh_lamc[jc + 1];
+                [[maybe_unused]] const float isig0 = sh_isig[jc], isig1 = sh_isig[jc + 1];
+                [[maybe_unused]] const float lconst = RTLL ? 0.0f : 2.0f * (float)LOG_2PI + (float)sh_lsig[jc] + (float)sh_lsig[jc + 1];
                 double S0[NSTAT], S1[NSTAT];
 #pragma unroll
                 for (int q = 0; q < NSTAT; ++q) { S0[q] = 0.0; S1[q] = 0.0; }
@@ -1623,7 +1664,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                             if (A.mode == 1) {
                                 const float eta = a * (th - b);
                                 float t = (y ? eta : 0.0f) - log1pexp_r(eta);
-                                if (fam_rt(MODEL) || fam_lq(MODEL)) {
+                                if constexpr (!RTLL && (fam_rt(MODEL) || fam_lq(MODEL))) {
                                     const float er = c + ze - lamc;
                                     t = fmaf(-0.5f * er * er, isig, t);
                                 }
@@ -1636,7 +1677,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                     }
 #pragma unroll
                     for (int q = 0; q < NSTAT; ++q) { S0[q] += (double)bs0[q]; S1[q] += (double)bs1[q]; }
-                    if (A.mode == 1 && (fam_rt(MODEL) || fam_lq(MODEL))) bl = fmaf(-0.5f * (float)nrow, lconst, bl);
+                    if constexpr (!RTLL) { if (A.mode == 1 && (fam_rt(MODEL) || fam_lq(MODEL))) bl = fmaf(-0.5f * (float)nrow, lconst, bl); }
                     llc += (double)bl;
                 }
 #pragma unroll
@@ -1644,6 +1685,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 if (jv && half == 0) {
 #pragma unroll
                     for (int q = 0; q < NSTAT; ++q) { acc[q * J + j0] = S0[q]; acc[q * J + j0 + 1] = S1[q]; }
+                    if constexpr (RTLL) { if (A.mode == 1) llc = fma(-(double)isig1, S1[4], fma(-(double)isig0, S0[4], llc)); }
                 }
                 ll += llc;
             }
@@ -1708,7 +1750,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                             t = (y ? eta : 0.0) - (eta > 0.0 ? eta : 0.0);
                             bprod *= 1.0 + fm::exp_neg(fabs(eta));
                         } else t = (y ? eta : real(0)) - log1pexp_r(eta);
-                        if (fam_rt(MODEL) || fam_lq(MODEL)) {
+                        if constexpr (!rtll_stats<MODEL, PHASE>() && (fam_rt(MODEL) || fam_lq(MODEL))) {
                             const real er = c + ze - lamc;
                             t += real(-0.5) * ((real)LOG_2PI + lsig + er * er * isig);
                         }
@@ -1770,6 +1812,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         if (jv) {
 #pragma unroll
             for (int q = 0; q < NSTAT; ++q) acc[q * J + j] = S[q];
+            if constexpr (rtll_stats<MODEL, PHASE>()) { if (A.mode == 1) llc = fma(-(double)isig, S[4], llc); }
         }
         ll += llc;
     }
@@ -1926,6 +1969,7 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_kernel(TinyArgs T)
     if (STEP == 0 && tid == 0 && !first && T.tr_ll) {
         double llv = st0[NS0 - 1];
         if (fam_cq(MODEL)) llv += st1[NS1 - 1];
+        if (rtll_stats<MODEL, 0>()) llv += lp[par_off_derived(J) + 1];         // ERM_RTLL_STATS: the subject-free part, left by the tiny step that drew the sweep's lambda / sig2t
         T.tr_ll[prev_row] = llv;
     }
     if (T.mode == 1) return;

@@ -766,7 +766,7 @@ template <typename real> struct Engine : EngineBase {
         if (turn.owns_lock()) turn.unlock();
         if (*h_tmo != 0u) {
             g_err = "the persistent sweep kernel timed out waiting for another workgroup's statistics (its workgroups were not all resident)";
-            return ERM_PERSIST_TIMEOUT;
+            return persistent_run ? ERM_PERSIST_TIMEOUT : fail(ERM_ERR_STATE, "internal: " + g_err);
         }
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -1448,6 +1448,7 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamSynchronize(stream));
         cfg.seed = seed;
+        sweeps_total = 0;            // a new seed starts a new chain: its streams are addressed from sweep 1, as a freshly created engine's are
         drop_graphs();               // the captured launches carry the seed as a kernel argument
         stats_valid = false;         // the resident omega_{t+1} / nu_{t+1} were drawn from the old streams: the next run draws them again
         return 0;

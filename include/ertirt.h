@@ -123,7 +123,8 @@ int erm_get_state(erm_handle h, erm_state* st);
  * runs `nsweeps` sweeps continuing from the current state; sweeps fill trace rows in order. */
 int erm_run(erm_handle h, int64_t nsweeps);
 /* A new seed for the chain's random streams (a simulation study re-uses ONE engine for all replications of a condition: src/SimTools.jl:457-495 constructs a
- * fresh sampler per replication, which draws from Julia's global stream).  Takes effect with the next erm_run. */
+ * fresh sampler per replication, which draws from Julia's global stream).  Takes effect with the next erm_run, which then draws the chain a freshly created
+ * engine with this seed would draw from the same data and state (the sweep counter that addresses the streams starts over). */
 int erm_set_seed(erm_handle h, uint64_t seed);
 int64_t erm_rows_done(erm_handle h);
 int erm_reset_trace(erm_handle h);   /* forget recorded rows and running means (state is kept) */

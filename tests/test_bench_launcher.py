@@ -115,3 +115,8 @@ def test_gpus_n_measures_the_c_abi_chain_farm():
     assert out["roofline"]["launches_timed"] >= 8 and out["roofline"]["algorithmic_bytes_per_cell_update"] == 25
     assert out["configs4_value"] == out["configs4"]["value"] > 0 and "nItem=100" in out["configs4"]["workload"] and "nChain=2" in out["configs4"]["workload"]
     assert len(out["configs4"]["per_chain_device_ms_per_step"]) == 2
+    # the run validates itself (a multi-GPU run exits non-zero otherwise): the library's communicator spans the farm's devices (one here), the farm's
+    # Post.mean is the count-weighted mean of the same chains run as separate engines, the per-chain timing check needs distinct devices and is left out
+    sc = out["self_check"]
+    assert sc["ok"] and sc["rccl_ranks"] == sc["rccl_ranks_expected"] == 1 and sc["farm_mean_vs_separate_engines_max_rel_err"] <= 1e-12 and sc["post_rows"] == sc["post_rows_expected"] == 2 * 16
+    assert "not a BASELINE.json configuration" in c["workload"]

@@ -127,7 +127,7 @@ def test_run_simulation_like_the_reference():
     Cond = pkg.setCond(nSubj=800, nItem=10, nFeat=2, nIter=300, nChain=1, nRep=3)
     tp = pkg.setTrueParaRtIrt(Cond, seed=3)
     Run = pkg.runSimulation(Cond, tp, Para=("a", "b", "λ", "σ²t"), funcData=pkg.setDataRtIrt, funcGibbs=pkg.GibbsRtIrt)
-    assert set(Run) == {"True", 1, 2, 3} and set(Run[1]) == {"a", "b", "λ", "σ²t", "Dic", "Diag"}
+    assert set(Run) == {"True", 1, 2, 3} and set(Run[1]) == {"a", "b", "λ", "σ²t", "Dic", "Diag", "Seconds"}
     assert np.isfinite(Run[2]["Dic"][0]) and " / " in Run[3]["Diag"]["essN"]
     assert not np.array_equal(Run[1]["a"], Run[2]["a"])                      # different data sets
     m = pkg.getMetrics(Run, par="b")
