@@ -65,7 +65,10 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
     f.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for r in rows[:4]:
         f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |\n")
-    f.write(f"\nbench line of the same run: ms_per_step {bench['ms_per_step']:.4f}, roofline {json.dumps(bench.get('roofline'))}\n\n")
+    rf = bench.get("roofline") or {}
+    f.write(f"\nbench line of the PROFILED run: ms_per_step {bench['ms_per_step']:.4f}, live launch_us {rf.get('launch_us', float('nan')):.2f} (HIP events around replayed graphs of the sweep "
+            f"kernel: under rocprofv3's kernel tracing the launches of a graph run several microseconds apart and the brackets include those gaps; the kernel's own average "
+            f"duration is the table's, and the unprofiled line -- profiles/{tag.rsplit('_', 1)[0]}_bench_line.json -- is the one whose live figure agrees with it)\n\n")
     f.write(f"pass_kernel HBM-side traffic per launch: FETCH_SIZE {fetch:.0f} KB x {corr:.2f} (calibrated) + WRITE_SIZE {write:.0f} KB = {traffic/1e6:.1f} MB "
             f"(algorithmic {BYTES*N*J/1e6:.1f} MB)\n")
     if valu:
