@@ -95,3 +95,27 @@ def test_farm_dic_is_the_dic_of_the_pooled_chains():
     assert abs(d["Dbar"] - Dbar) <= 1e-12 * abs(Dbar) and abs(d["Dhat"] - Dhat) <= 1e-10 * abs(Dhat)
     assert pkg.getDic(M).DIC == d["DIC"]
     M.close()
+
+
+@pytest.mark.parametrize("model", ["rtirt", "crossqr"])
+def test_dic_at_baseline_size_matches_the_host_evaluation(model):
+    """BASELINE.json's size (100 000 x 50): the device DIC of a summary-trace engine against the numpy evaluation of getLogLikelihood at the pulled Post.mean
+    and the pulled logLike rows -- for GibbsRtIrtCrossQr that includes the 5 000 000 means of nu the device evaluation never moves."""
+    pkg = pu.ge.load_package()
+    L = pkg._lib
+    N, J, rows, burn = 100_000, 50, 12, 4
+    Y, logT, X, init, tp = pu.make_problem(model, N, J, 3, seed=21)
+    r = pu.run_device(model, Y, logT, X, init, rows, precision="f64", trace_full=False, n_burnin=burn)
+    eng = r["engine"]
+    d = eng.dic()
+    m = eng.get_mean()
+    Cond = pkg.setCond(nSubj=N, nItem=J, nFeat=3, nIter=rows, nChain=1, qRt=0.85)
+    M = getattr(pkg, CLS[model])(Cond, Data=pkg.InputData(Y=Y, T=np.exp(logT), X=X if X is not None else np.zeros((N, 3))))
+    P = pkg.InputPara(theta=m["theta"], a=m["a"], b=m["b"], zeta=m["zeta"], lam=m["lambda_"], sig2t=m["sig2t"], Sigp=m["sigp"])
+    for k_src, k_dst in (("beta", "beta"), ("rho", "rho"), ("nu", "nu")):
+        if m.get(k_src) is not None:
+            setattr(P, k_dst, m[k_src])
+    Dhat = -2.0 * pkg.getLogLikelihood(M, P)
+    Dbar = -2.0 * float(np.mean(r["ll"]))
+    assert abs(d["Dhat"] - Dhat) <= 1e-10 * abs(Dhat) and abs(d["Dbar"] - Dbar) <= 1e-12 * abs(Dbar)
+    eng.close()
