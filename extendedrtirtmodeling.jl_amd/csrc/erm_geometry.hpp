@@ -63,7 +63,7 @@ inline size_t pass_lds(const GeomIn& g, int phase, int nWaves, long long rows_pe
 {
     const int ngl = stat_size(g, phase) - nstat(g, phase) * g.J;
     const size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * (size_t)ngl;
-    return d * sizeof(double) + ((size_t)NITEMARR * g.J + (size_t)nWaves * 4 * (size_t)rows_per_wave + (size_t)rows_per_block * (size_t)(g.Fk + 4)) * real_size(g) + 8 + tail_lds(g, phase, nWaves);
+    return d * sizeof(double) + ((size_t)NITEMARR * g.J + (size_t)nWaves * 4 * (size_t)rows_per_wave + (size_t)rows_per_block * (size_t)nv_of(g.model, g.Fk)) * real_size(g) + 8 + tail_lds(g, phase, nWaves);
 }
 inline size_t fused_extra(const GeomIn& g) { return 8 + (size_t)(2 * stat_size(g, 0) + TINY_WORK + 2 * PMAX * PMAX + par_size(g.J) + 3 * g.J + 2) * sizeof(double); }
 }  // namespace geom_detail

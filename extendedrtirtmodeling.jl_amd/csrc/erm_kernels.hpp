@@ -745,7 +745,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
     real* sh_rs = sh_item + NITEMARR * J;                                          // [rows_per_block][3] row sums, indexed by the subject's position in the workgroup
                                                                                    // (the region holds nWaves * 4 * rows_per_wave >= 4 * rows_per_block values)
-    const int NV = A.nFeat + 4;
+    const int NV = nv_of(MODEL, A.nFeat);
     real* sh_val = sh_item + NITEMARR * J + (size_t)nWaves * 4 * A.rows_per_wave;   // [rows_per_block][NV] per-subject values of the global statistics
 
     // diagnostics: per-wave phase timeline of workgroups 0 and gridDim/2 (lane 0 of each wave stamps the constant-rate wall clock)
@@ -1266,7 +1266,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         if ((NG > 1 || PHASE == 0) && rok) {
             real* o = sh_val + (size_t)(i - row0) * NV;
             for (int u = 1; u <= F; ++u) o[u - 1] = xcol(u);
-            o[F] = th; o[F + 1] = ze; o[F + 2] = ze - k1 * nu_next; o[F + 3] = nu_next;
+            o[F] = th; o[F + 1] = ze;
+            if constexpr (fam_lq(MODEL)) { o[F + 2] = ze - k1 * nu_next; o[F + 3] = nu_next; }
         }
     }
     stamp(6);

@@ -22,6 +22,10 @@ ERM_HD constexpr bool fam_cq(int M) { return M == CROSSQR || M == CROSS; }     /
 ERM_HD constexpr bool has_nu(int M) { return M == CROSSQR || M == LATENTQR; }
 
 constexpr int PMAX = 16;            // max columns of the latent-regression design ([1 X theta])
+// per-subject values parked in LDS for the global statistics (pass_kernel, sh_val): the X row, theta, zeta -- and, where the latent regression of zeta on
+// [1 X theta] needs them (Latent family), u = zeta - k1 nu and nu.  Round 4: the two extra slots only where they are read (16 B per subject in fp64: a
+// 500 000 x 100 GibbsRtIrt chain fits two rounds of workgroups instead of three)
+ERM_HD constexpr int nv_of(int M, int nFeat) { return nFeat + (fam_lq(M) ? 4 : 2); }
 constexpr int NITEMARR = 8;         // per-item arrays staged in LDS
 constexpr int MAX_ITEMS = 896;      // n_item limit of the engine
 
