@@ -745,6 +745,13 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
     real* sh_rs = sh_item + NITEMARR * J;                                          // [rows_per_block][3] row sums, indexed by the subject's position in the workgroup
                                                                                    // (the region holds nWaves * 4 * rows_per_wave >= 4 * rows_per_block values)
+    // the per-item product of the cell streams' Philox blocks (philox4x32_10_vk_cell), one uint2 per item, in the two item arrays these models never read
+    // (log sig2t: the response-time log-likelihood comes from statistics; rho: the Cross family's) -- 2 J reals = J uint2 in either engine
+#ifndef ERM_PHILOX_HOIST
+#define ERM_PHILOX_HOIST 1
+#endif
+    constexpr bool PHX = ERM_PHILOX_HOIST != 0 && PHASE == 0 && !fam_cq(MODEL) && (MODEL == MLIRT || rtll_stats<MODEL, PHASE>());
+    [[maybe_unused]] uint2* sh_phx = reinterpret_cast<uint2*>(sh_lsig);
     const int NV = nv_of(MODEL, A.nFeat);
     real* sh_val = sh_item + NITEMARR * J + (size_t)nWaves * 4 * A.rows_per_wave;   // [rows_per_block][NV] per-subject values of the global statistics
 
@@ -951,12 +958,13 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
             const int jstep = rt_off ? 2 * Jw : nit;
             for (int j = tid - ioff; tid >= ioff && j < J; j += jstep) {
                 const double a = lp[j], b = lp[J + j];
-                sh_a[j] = (real)a; sh_b[j] = (real)b; sh_a2[j] = (real)(a * a); sh_a2b[j] = (real)(a * a * b); sh_rho[j] = (real)lp[4 * J + j];
+                sh_a[j] = (real)a; sh_b[j] = (real)b; sh_a2[j] = (real)(a * a); sh_a2b[j] = (real)(a * a * b);
+                if constexpr (PHX) sh_phx[j] = philox_item_product((uint32_t)j, sweep + 1u, (uint32_t)A.seed); else sh_rho[j] = (real)lp[4 * J + j];
             }
             for (int j = tid - ioff - rt_off; tid >= ioff + rt_off && j < J; j += jstep) {
                 const double lam = lp[2 * J + j], sg = lp[3 * J + j];
                 sh_lamc[j] = (real)(lam - lcst[cst_off_m(J) + j]); sh_isig[j] = (real)(1.0 / sg);
-                if constexpr (!rtll_stats<MODEL, PHASE>()) sh_lsig[j] = (real)log(sg);
+                if constexpr (!rtll_stats<MODEL, PHASE>() && !PHX) sh_lsig[j] = (real)log(sg);
             }
             if (tid == 0) { *reinterpret_cast<int*>(sh_struct + 5) = 0; *reinterpret_cast<unsigned int*>(sh_struct + 7) = 0u; }       // sh_ready, row-group counter
             for (int e = tid; e < nWaves * NG; e += nthr) sh_gacc[e] = 0.0;
@@ -974,7 +982,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     for (int j = threadIdx.x; j < J; j += blockDim.x) {
         const double a = parsrc[j], b = parsrc[J + j], lam = parsrc[2 * J + j], sg = parsrc[3 * J + j], rho = parsrc[4 * J + j];
         sh_a[j] = (real)a; sh_b[j] = (real)b; sh_a2[j] = (real)(a * a); sh_a2b[j] = (real)(a * a * b);
-        sh_lamc[j] = (real)(lam - (FUSED ? lcst[cst_off_m(J) + j] : A.cst[cst_off_m(J) + j])); sh_isig[j] = (real)(1.0 / sg); sh_lsig[j] = (real)log(sg); sh_rho[j] = (real)rho;
+        sh_lamc[j] = (real)(lam - (FUSED ? lcst[cst_off_m(J) + j] : A.cst[cst_off_m(J) + j])); sh_isig[j] = (real)(1.0 / sg);
+        if constexpr (PHX) sh_phx[j] = philox_item_product((uint32_t)j, sweep + 1u, (uint32_t)A.seed); else { sh_lsig[j] = (real)log(sg); sh_rho[j] = (real)rho; }
     }
     if (FUSED && threadIdx.x == 0) *sh_ready = 0;
     if (!FUSED && threadIdx.x < 8 + 2 * PMAX) {
@@ -1303,6 +1312,17 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         int kb = pg_bin_index(z);                     // the cell's row of the proposal table
         real* om = A.omega + (size_t)qrow0 * J;
         const uint32_t c3 = ((uint32_t)SITE_OMEGA << 24) | ((A.chain & 0xFFu) << 16);
+        // PHX: what a cell fixes of its attempts' Philox blocks (philox4x32_10_vk_cell), made when the cell is taken
+        [[maybe_unused]] uint32_t ph_hi = 0u, ph_m2 = 0u, ph_m3 = 0u;
+        [[maybe_unused]] const uint32_t ph_n1k = (uint32_t)((uint64_t)0xCD9E8D57u * (sweep + 1u)) ^ ((uint32_t)A.seed + 0x9E3779B9u);
+        auto cell_words = [&](int rr_, int j_) {
+            if constexpr (PHX) {
+                const uint64_t p0 = (uint64_t)0xD2511F53u * ((uint32_t)(qrow0 + rr_) + A.row_base);
+                const uint2 pj = sh_phx[j_];
+                ph_hi = (uint32_t)(p0 >> 32); ph_m2 = pj.x ^ (uint32_t)p0 ^ ((uint32_t)(A.seed >> 32) + 0xBB67AE85u); ph_m3 = pj.y;
+            }
+        };
+        if (active) cell_words(rr, j);
         [[maybe_unused]] unsigned int n_att = 0, n_trip = 0;
 #ifndef ERM_PG_VKEYS
 #define ERM_PG_VKEYS 8
@@ -1324,7 +1344,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
 #endif
             if (active) {
                 uint32_t w0, w1, w2, w3;
-                philox4x32_10_vk<NVK>((uint32_t)(qrow0 + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), pgk, w0, w1, w2, w3);
+                if constexpr (PHX) philox4x32_10_vk_cell<NVK>(ph_hi, ph_m2, ph_m3, c3 | att, ph_n1k, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), pgk, w0, w1, w2, w3);
+                else philox4x32_10_vk<NVK>((uint32_t)(qrow0 + rr) + A.row_base, (uint32_t)j, sweep + 1u, c3 | att, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), pgk, w0, w1, w2, w3);
                 real w;
                 bool acc_, unsure;
                 if constexpr (sizeof(real) == 8) acc_ = pg1_attempt_f64<true>(z, w0, w1, w2, w3, sh_pgf[kb], sh_pgc[kb], logtab, w, unsure);
@@ -1341,7 +1362,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                     c = (int)atomicAdd(qhead, 1u);
                     att = 0;
                     active = c < ncell;
-                    if (active) { locate(c, rr, j); th = theta_of(rr); z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); kb = pg_bin_index(z); }
+                    if (active) { locate(c, rr, j); th = theta_of(rr); z = real(0.5) * r_abs(sh_a[j] * (th - sh_b[j])); kb = pg_bin_index(z); cell_words(rr, j); }
                 } else ++att;
             }
         }

@@ -221,6 +221,42 @@ __device__ __forceinline__ void philox4x32_10_vk(uint32_t c0, uint32_t c1, uint3
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
+// The same block for the cell streams of the row pass, counter (i, j, c2, S | attempt): rounds 0 and 1 multiply words that do not depend on the attempt --
+// M0 i (the subject), M1 c2 (uniform) and M0 (hi(M1 c2) ^ j ^ k0) (the item, once per sweep: philox_item_product) -- so a cell fixes two of round 1's four output
+// words when it is taken from the queue (m2 = hi(item product) ^ lo(M0 i) ^ (k1 + G1), m3 = lo(item product)) and an attempt spends ONE 32 x 32 -> 64 multiplication on
+// rounds 0-1 instead of three (v_mad_u64_u32 issues in 9 cycles: profiles/round4_valu_issue_rates.txt).  s_n1k = lo(M1 c2) ^ (k0 + G0).  Same words, bit for bit.
+__device__ __forceinline__ uint2 philox_item_product(uint32_t j, uint32_t c2, uint32_t k0)
+{
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ j ^ k0;
+    const uint64_t pj = (uint64_t)0xD2511F53u * n0;
+    return make_uint2((uint32_t)(pj >> 32), (uint32_t)pj);
+}
+template <int NV>
+__device__ __forceinline__ void philox4x32_10_vk_cell(uint32_t p0hi, uint32_t m2, uint32_t m3, uint32_t c3w, uint32_t s_n1k, uint32_t k0, uint32_t k1,
+                                                      const uint32_t (&kv)[NV > 0 ? NV : 1], uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+    uint32_t n2;
+    if (1 < NV) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"(p0hi), "v"(c3w), "v"(kv[1 < NV ? 1 : 0]));
+    else asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"(p0hi), "v"(c3w), "s"(k1));
+    const uint64_t q1 = (uint64_t)0xCD9E8D57u * n2;
+    uint32_t c0 = (uint32_t)(q1 >> 32) ^ s_n1k, c1 = (uint32_t)q1, c2 = m2, c3 = m3;
+    k0 += 2u * 0x9E3779B9u; k1 += 2u * 0xBB67AE85u;
+#pragma unroll
+    for (int r = 2; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0, n2_;
+        if (2 * r < NV) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"((uint32_t)(p1 >> 32)), "v"(c1), "v"(kv[2 * r < NV ? 2 * r : 0]));
+        else asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"((uint32_t)(p1 >> 32)), "v"(c1), "s"(k0));
+        if (2 * r + 1 < NV) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2_) : "v"((uint32_t)(p0 >> 32)), "v"(c3), "v"(kv[2 * r + 1 < NV ? 2 * r + 1 : 0]));
+        else asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2_) : "v"((uint32_t)(p0 >> 32)), "v"(c3), "s"(k1));
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2_;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
 struct Stream {
     uint32_t k0, k1, c0, c1, c2, c3;   // c3 holds site/chain in the top 16 bits, block index below
     uint32_t b0, b1, b2, b3;
