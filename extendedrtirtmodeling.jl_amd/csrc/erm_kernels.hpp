@@ -1072,6 +1072,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                     ok4[u] = rowok && (k0 + u) < IPP && q < P;
                     jv4[u] = ok4[u] ? 2 * q : 0;
                     const unsigned int e = base + (unsigned int)jv4[u];
+                    // (plain element offsets here: 32-bit BYTE offsets from the scalar base, which pay in the column phase below, cost the fp32 engine 1.2 us per
+                    // sweep in this loop and change nothing in the fp64 one -- profiles/round4_ab_address_arithmetic.log)
                     if constexpr (PHASE == 0) { wv[u] = *reinterpret_cast<const real2*>(blk_omega + e); yv[u] = *reinterpret_cast<const unsigned short*>(blk_Y + e); }
                     else { yv[u] = 0u; if constexpr (has_nu(MODEL)) wv[u] = *reinterpret_cast<const real2*>(blk_nu + e); else { wv[u].x = real(1); wv[u].y = real(1); } }
                     if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const real2*>(blk_C + e); else { cv[u].x = real(0); cv[u].y = real(0); }
@@ -1081,7 +1083,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                     const int j = jv4[u];
                     const real m = ok4[u] ? real(1) : real(0);
                     if constexpr (PHASE == 0) {
-                        const real kap0 = (real)(yv[u] & 0xFFu) - real(0.5), kap1 = (real)(yv[u] >> 8) - real(0.5);
+                        const real kap0 = (yv[u] & 0xFFu) ? real(0.5) : real(-0.5), kap1 = (yv[u] >> 8) ? real(0.5) : real(-0.5);      // Y is 0/1 (erm_set_data checks): y - 1/2 by a select, not a conversion
                         s0 += m * (sh_a2[j] * wv[u].x + sh_a2[j + 1] * wv[u].y);
                         s1 += m * ((sh_a[j] * kap0 + sh_a2b[j] * wv[u].x) + (sh_a[j + 1] * kap1 + sh_a2b[j + 1] * wv[u].y));
                         if (fam_rt(MODEL) || fam_lq(MODEL)) s2 += m * ((sh_lamc[j] - cv[u].x) * sh_isig[j] + (sh_lamc[j + 1] - cv[u].y) * sh_isig[j + 1]);
@@ -1358,7 +1360,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 if (acc_ || att + 1u >= (uint32_t)MAX_TRIES) {
                     // write-through (sc1) store: omega_{t+1} is next read by the column phase (behind a barrier) and by the next launch, and nothing of it
                     // stays dirty in L2 for the end-of-kernel write-back (A/B on one box: 75.9-76.2 -> 75.4-75.7 us per sweep)
-                    __hip_atomic_store(om + c, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(reinterpret_cast<real*>(reinterpret_cast<char*>(om) + (unsigned int)c * (unsigned int)sizeof(real)), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     c = (int)atomicAdd(qhead, 1u);
                     att = 0;
                     active = c < ncell;
@@ -1588,12 +1590,18 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                         const int q = q0 - (2 * u + half);
                         okv[u] = jv && q < nrows_blk;
                         const int qc = q < nrows_blk ? q : 0;
-                        const unsigned int e = (unsigned int)qc * (unsigned int)J + (unsigned int)jc;      // < 2^22: 32-bit offsets from the workgroup's first cell
-                        thv[u] = blk_theta[qc];
-                        zev[u] = (MODEL != MLIRT) ? blk_zeta[qc] : 0.0;
-                        wv[u] = *reinterpret_cast<const double2*>(blk_omega + e);
+                        // (24-bit multiplications: full rate, and a position in the workgroup, nItem and NV are all far below 2^24; the 32-bit multiply-add
+                        // the compiler otherwise takes is a v_mad_u64_u32, three times the issue cost)
+                        const unsigned int e = __umul24((unsigned int)qc, (unsigned int)J) + (unsigned int)jc;      // < 2^22: 32-bit offsets from the workgroup's first cell
+                        // theta_t, zeta_t of the subject: parked in LDS by the subject draws (a broadcast read per half-wave instead of two global loads);
+                        // omega and logT at 32-bit BYTE offsets from the workgroup's (scalar) base -- one shift instead of three 64-bit vector operations per load
+                        const real* sv = sh_val + __umul24((unsigned int)qc, (unsigned int)NV) + F;
+                        thv[u] = sv[0];
+                        zev[u] = (MODEL != MLIRT) ? sv[1] : 0.0;
+                        const unsigned int e8 = e << 3;
+                        wv[u] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(blk_omega) + e8);
                         yv[u] = *reinterpret_cast<const unsigned short*>(blk_Y + e);
-                        if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const double2*>(blk_C + e); else { cv[u].x = 0.0; cv[u].y = 0.0; }
+                        if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(blk_C) + e8); else { cv[u].x = 0.0; cv[u].y = 0.0; }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -1665,12 +1673,14 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                         const int q = q0 - (2 * u + half);
                         okv[u] = jv && q < nrows_blk;
                         const int qc = q < nrows_blk ? q : 0;
-                        const unsigned int e = (unsigned int)qc * (unsigned int)J + (unsigned int)jc;
-                        thv[u] = blk_theta[qc];
-                        zev[u] = (MODEL != MLIRT) ? blk_zeta[qc] : 0.0f;
-                        wv[u] = *reinterpret_cast<const float2*>(blk_omega + e);
+                        const unsigned int e = __umul24((unsigned int)qc, (unsigned int)J) + (unsigned int)jc;
+                        const real* sv = sh_val + __umul24((unsigned int)qc, (unsigned int)NV) + F;      // (as in the fp64 loop above)
+                        thv[u] = sv[0];
+                        zev[u] = (MODEL != MLIRT) ? sv[1] : 0.0f;
+                        const unsigned int e4 = e << 2;
+                        wv[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(blk_omega) + e4);
                         yv[u] = *reinterpret_cast<const unsigned short*>(blk_Y + e);
-                        if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const float2*>(blk_C + e); else { cv[u].x = 0.0f; cv[u].y = 0.0f; }
+                        if constexpr (MODEL != MLIRT) cv[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(blk_C) + e4); else { cv[u].x = 0.0f; cv[u].y = 0.0f; }
                     }
                     float bs0[NSTAT], bs1[NSTAT], bl = 0.0f;
 #pragma unroll

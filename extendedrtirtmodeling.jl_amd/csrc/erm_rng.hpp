@@ -129,15 +129,15 @@ __device__ __forceinline__ double cos2pi(double u)
 __device__ __forceinline__ double exp_neg(double a)
 {
     a = a < 700.0 ? a : 700.0;
-    const double k = __builtin_rint(a * 1.44269504088896340736);
-    double r = fma(-k, 0.693147180559945286227, a);               // ln2 = hi + lo with hi = double(ln2): the fma forms a - k hi exactly
-    r = fma(-k, 2.31904681384629955842e-17, r);
+    const double k = __builtin_rint(a * -1.44269504088896340736);     // -rint(a / ln2): the negated count goes straight into the reduction and the final scaling
+    double r = fma(k, 0.693147180559945286227, a);                // ln2 = hi + lo with hi = double(ln2): the fma forms a - |k| hi exactly
+    r = fma(k, 2.31904681384629955842e-17, r);
     const double t = -r;
     double P = 1.0 / 6227020800.0;
     P = fma(P, t, 1.0 / 479001600.0); P = fma(P, t, 1.0 / 39916800.0); P = fma(P, t, 1.0 / 3628800.0); P = fma(P, t, 1.0 / 362880.0);
     P = fma(P, t, 1.0 / 40320.0); P = fma(P, t, 1.0 / 5040.0); P = fma(P, t, 1.0 / 720.0); P = fma(P, t, 1.0 / 120.0); P = fma(P, t, 1.0 / 24.0);
     P = fma(P, t, 1.0 / 6.0); P = fma(P, t, 0.5); P = fma(P, t, 1.0); P = fma(P, t, 1.0);
-    return __builtin_amdgcn_ldexp(P, -(int)k);
+    return __builtin_amdgcn_ldexp(P, (int)k);
 }
 }  // namespace fm
 
