@@ -1614,7 +1614,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                                 const double eta = a * (th - b);
                                 const double sgn = y ? -eta : eta;                  // y eta - max(eta, 0) = -max(sgn, 0)
                                 lmax += sgn > 0.0 ? sgn : 0.0;
-                                bprod *= 1.0 + fm::exp_neg(fabs(eta));
+                                bprod *= 1.0 + fm::exp_neg_ll(fabs(eta));
                                 if constexpr (!RTLL && (fam_rt(MODEL) || fam_lq(MODEL))) {
                                     const double er = c + ze - lamc;
                                     rtq = fma(er * er, isig, rtq);
@@ -1780,7 +1780,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                         real t;
                         if constexpr (sizeof(real) == 8) {
                             t = (y ? eta : 0.0) - (eta > 0.0 ? eta : 0.0);
-                            bprod *= 1.0 + fm::exp_neg(fabs(eta));
+                            bprod *= 1.0 + fm::exp_neg_ll(fabs(eta));
                         } else t = (y ? eta : real(0)) - log1pexp_r(eta);
                         if constexpr (!rtll_stats<MODEL, PHASE>() && (fam_rt(MODEL) || fam_lq(MODEL))) {
                             const real er = c + ze - lamc;
