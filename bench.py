@@ -72,7 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--nitem", type=int, default=50)
     ap.add_argument("--nfeat", type=int, default=3)
     ap.add_argument("--precision", default="f64", choices=["f32", "f64"], help="engine of the headline value (default: the reference's Float64)")
-    ap.add_argument("--no-fp32", action="store_true", help="skip the nested fp32 fast-mode measurement")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the nested measurements (the fp32 fast mode; at N = 1 also the two chains sharing the GPU): ONE engine runs, "
+                                                             "which is what the profiling tools under tools/ want")
     ap.add_argument("--no-configs4", action="store_true", help="at N > 1: skip the nested measurement on configs[4]'s per-GPU load (500000 x 100)")
     ap.add_argument("--trace", default="full", choices=["full", "summary"])
     ap.add_argument("--lanes-per-row", type=int, default=0)
@@ -699,7 +700,7 @@ def main():
     # in its serial head, its subject draws and its tail; a second chain's launches fill them.  NOT the headline (`value` is one chain): the reference's default
     # is nChain = 4 (src/Base.pl.jl:59), so this is what a user's sample!(MCMC; devices=[0, 0]) gets per GPU.
     two = None
-    if world == 1 and dist is None and not args.no_two_chains and not shard:
+    if world == 1 and dist is None and not args.no_two_chains and not args.no_fp32 and not shard:
         a2 = argparse.Namespace(**vars(args))
         a2.no_cold = True
         dt2, _, ftm2, etm2, farm2 = measure_farm(pkg=pkg, torch=torch, dist=None, args=a2, n_dev=2, devices=[local_rank, local_rank], flags=0, rank=0, model=model, N=N, J=J, F=F,
