@@ -62,8 +62,8 @@ inline size_t tail_lds(const GeomIn& g, int phase, int nWaves) { return (size_t)
 inline size_t pass_lds(const GeomIn& g, int phase, int nWaves, long long rows_per_block, int rows_per_wave)
 {
     const int ngl = stat_size(g, phase) - nstat(g, phase) * g.J;
-    const size_t d = (size_t)(8 + 2 * PMAX) + (size_t)nWaves * (size_t)ngl;
-    return d * sizeof(double) + ((size_t)NITEMARR * g.J + (size_t)nWaves * 4 * (size_t)rows_per_wave + (size_t)rows_per_block * (size_t)nv_of(g.model, g.Fk)) * real_size(g) + 8 + tail_lds(g, phase, nWaves);
+    const size_t d = (size_t)(8 + 2 * PMAX) + (((size_t)nWaves * (size_t)ngl + 1) & ~(size_t)1);      // (an even count: the item arrays behind it are 16-byte aligned)
+    return d * sizeof(double) + ((size_t)NITEMARR * item_stride(g.J) + (size_t)nWaves * 4 * (size_t)rows_per_wave + (size_t)rows_per_block * (size_t)nv_of(g.model, g.Fk)) * real_size(g) + 8 + tail_lds(g, phase, nWaves);
 }
 inline size_t fused_extra(const GeomIn& g) { return 8 + (size_t)(2 * stat_size(g, 0) + TINY_WORK + 2 * PMAX * PMAX + par_size(g.J) + 3 * g.J + 2) * sizeof(double); }
 }  // namespace geom_detail
@@ -107,7 +107,7 @@ inline int plan_geometry_core(const GeomIn& g, Geom& out, std::string& err)
         // the per-wave item accumulators (nWaves x NSTAT x nItem doubles) dominate LDS for long tests: fewer waves per workgroup then
         while (bt > 64) {
             const size_t acc = (size_t)(bt / 64) * nstat(g, 0) * J * sizeof(double);
-            const size_t fixed = (size_t)NITEMARR * J * real_size(g) + (size_t)(o.ns[0] + 5 * J + 2 * J + TINY_WORK + 2 * PMAX * PMAX + 64) * sizeof(double);
+            const size_t fixed = (size_t)NITEMARR * item_stride(J) * real_size(g) + (size_t)(o.ns[0] + 5 * J + 2 * J + TINY_WORK + 2 * PMAX * PMAX + 64) * sizeof(double);
             if (acc + fixed + stat_max <= 120 * 1024) break;
             bt = std::max(64, bt / 2 / 64 * 64);
         }

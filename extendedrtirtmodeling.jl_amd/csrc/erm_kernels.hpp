@@ -740,10 +740,11 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     // the per-wave item accumulators close the launch's dynamic LDS (A.acc_off)
     double* sh_acc = reinterpret_cast<double*>(smem + A.acc_off);    // [nWaves][NSTAT][J]
     double* sh_gacc = sh_struct + 8 + 2 * PMAX;                 // [nWaves][NG]
-    real* sh_item = reinterpret_cast<real*>(sh_gacc + (size_t)nWaves * NG);    // [NITEMARR][J]
-    real* sh_a = sh_item, *sh_b = sh_item + J, *sh_a2 = sh_item + 2 * J, *sh_a2b = sh_item + 3 * J;
-    real* sh_lamc = sh_item + 4 * J, *sh_isig = sh_item + 5 * J, *sh_lsig = sh_item + 6 * J, *sh_rho = sh_item + 7 * J;
-    real* sh_rs = sh_item + NITEMARR * J;                                          // [rows_per_block][3] row sums, indexed by the subject's position in the workgroup
+    real* sh_item = reinterpret_cast<real*>(sh_gacc + (((size_t)nWaves * NG + 1) & ~(size_t)1));    // [NITEMARR][JS], JS = item_stride(J) >= J (erm_layout.hpp); 16-byte aligned
+    const int JS = item_stride(J);
+    real* sh_a = sh_item, *sh_b = sh_item + JS, *sh_a2 = sh_item + 2 * JS, *sh_a2b = sh_item + 3 * JS;
+    real* sh_lamc = sh_item + 4 * JS, *sh_isig = sh_item + 5 * JS, *sh_lsig = sh_item + 6 * JS, *sh_rho = sh_item + 7 * JS;
+    real* sh_rs = sh_item + NITEMARR * JS;                                         // [rows_per_block][3] row sums, indexed by the subject's position in the workgroup
                                                                                    // (the region holds nWaves * 4 * rows_per_wave >= 4 * rows_per_block values)
     // the per-item product of the cell streams' Philox blocks (philox4x32_10_vk_cell), one uint2 per item, in the two item arrays these models never read
     // (log sig2t: the response-time log-likelihood comes from statistics; rho: the Cross family's) -- 2 J reals = J uint2 in either engine
@@ -755,7 +756,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
     constexpr bool PHX = ERM_PHILOX_HOIST != 0 && !PERSIST && PHASE == 0 && !fam_cq(MODEL) && (MODEL == MLIRT || rtll_stats<MODEL, PHASE>());
     [[maybe_unused]] uint2* sh_phx = reinterpret_cast<uint2*>(sh_lsig);
     const int NV = nv_of(MODEL, A.nFeat);
-    real* sh_val = sh_item + NITEMARR * J + (size_t)nWaves * 4 * A.rows_per_wave;   // [rows_per_block][NV] per-subject values of the global statistics
+    real* sh_val = sh_item + NITEMARR * JS + (size_t)nWaves * 4 * A.rows_per_wave;   // [rows_per_block][NV] per-subject values of the global statistics
 
     // diagnostics: per-wave phase timeline of workgroups 0 and gridDim/2 (lane 0 of each wave stamps the constant-rate wall clock)
     // (compiled in only with -DERM_TIMELINE_BUILD: even the disabled checks cost registers and ~3 us per sweep)
@@ -1057,6 +1058,9 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         // the fp32 engine's 8-byte pairs gained nothing and stay on the scalar path)
         using real2 = typename std::conditional<sizeof(real) == 8, double2, float2>::type;
         const int P = J >> 1, IPP = (P + W - 1) / W;
+        // the loop twice: with the item arrays' stride a compile-time constant (test lengths up to ITEM_STRIDE: the arrays' reads share one address) and as a variable
+        auto pair_sums = [&](auto jsc) {
+        const int js = jsc;
         for (;;) {
             const int g = next_group();
             if (g >= ngroups) break;
@@ -1084,16 +1088,22 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 for (int u = 0; u < KB; ++u) {
                     const int j = jv4[u];
                     const real m = ok4[u] ? real(1) : real(0);
+                    // the item pair's entries of every array, each ONE aligned real2 read: it + k * js (a, b, a^2, a^2 b, lambda - mean, 1/sig2t, log sig2t, rho); j is even,
+                    // the arrays' base and stride are multiples of 16 bytes
+                    const real* it = reinterpret_cast<const real*>(__builtin_assume_aligned(sh_item + j, sizeof(real2)));
+                    auto pair_of = [&](int k) -> real2 { return *reinterpret_cast<const real2*>(it + k * js); };
                     if constexpr (PHASE == 0) {
                         const real kap0 = (yv[u] & 0xFFu) ? real(0.5) : real(-0.5), kap1 = (yv[u] >> 8) ? real(0.5) : real(-0.5);      // Y is 0/1 (erm_set_data checks): y - 1/2 by a select, not a conversion
-                        s0 += m * (sh_a2[j] * wv[u].x + sh_a2[j + 1] * wv[u].y);
-                        s1 += m * ((sh_a[j] * kap0 + sh_a2b[j] * wv[u].x) + (sh_a[j + 1] * kap1 + sh_a2b[j + 1] * wv[u].y));
-                        if (fam_rt(MODEL) || fam_lq(MODEL)) s2 += m * ((sh_lamc[j] - cv[u].x) * sh_isig[j] + (sh_lamc[j + 1] - cv[u].y) * sh_isig[j + 1]);
+                        const real2 pa = pair_of(0), pa2 = pair_of(2), pa2b = pair_of(3);
+                        s0 += m * (pa2.x * wv[u].x + pa2.y * wv[u].y);
+                        s1 += m * ((pa.x * kap0 + pa2b.x * wv[u].x) + (pa.y * kap1 + pa2b.y * wv[u].y));
+                        if (fam_rt(MODEL) || fam_lq(MODEL)) { const real2 pl = pair_of(4), ps = pair_of(5); s2 += m * ((pl.x - cv[u].x) * ps.x + (pl.y - cv[u].y) * ps.y); }
                     } else {   // Cross family pass B: zeta sums with per-cell nu weights (src/Draw.pl.jl:201-202)
+                        const real2 pl = pair_of(4), ps = pair_of(5), pr = pair_of(7);
                         const real nu0 = ok4[u] ? wv[u].x : real(1), nu1 = ok4[u] ? wv[u].y : real(1);
-                        const real id0 = r_div(sh_isig[j], k2 * nu0), id1 = r_div(sh_isig[j + 1], k2 * nu1);
+                        const real id0 = r_div(ps.x, k2 * nu0), id1 = r_div(ps.y, k2 * nu1);
                         s0 += m * (id0 + id1);
-                        s2 += m * ((sh_lamc[j] - cv[u].x - thr * sh_rho[j] + k1 * nu0) * id0 + (sh_lamc[j + 1] - cv[u].y - thr * sh_rho[j + 1] + k1 * nu1) * id1);
+                        s2 += m * ((pl.x - cv[u].x - thr * pr.x + k1 * nu0) * id0 + (pl.y - cv[u].y - thr * pr.y + k1 * nu1) * id1);
                     }
                 }
             }
@@ -1101,6 +1111,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
             if (PHASE == 0) s1 = bfly_sum(s1, 1, W);
             if (rowok && s == 0) { real* o = sh_rs + 3 * qrow; o[0] = s0; o[1] = s1; o[2] = s2; }
         }
+        };
+        if (ITEM_STRIDE > 0 && JS == ITEM_STRIDE) pair_sums(std::integral_constant<int, ITEM_STRIDE>{}); else pair_sums(JS);
     } else if (A.mode == 1) {
         for (;;) {
             const int g = next_group();

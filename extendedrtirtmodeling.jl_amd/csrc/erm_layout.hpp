@@ -27,6 +27,13 @@ constexpr int PMAX = 16;            // max columns of the latent-regression desi
 // 500 000 x 100 GibbsRtIrt chain fits two rounds of workgroups instead of three)
 ERM_HD constexpr int nv_of(int M, int nFeat) { return nFeat + (fam_lq(M) ? 4 : 2); }
 constexpr int NITEMARR = 8;         // per-item arrays staged in LDS
+// ... at a stride the row-sum loop knows at compile time for the usual test lengths: its five arrays are then read at immediate offsets from ONE address per item pair
+// (one vector add per array and pair otherwise: a sixth of that loop's instructions)
+#ifndef ERM_ITEM_STRIDE
+#define ERM_ITEM_STRIDE 128
+#endif
+constexpr int ITEM_STRIDE = ERM_ITEM_STRIDE;
+ERM_HD constexpr int item_stride(int J) { return (ITEM_STRIDE > 0 && J <= ITEM_STRIDE) ? ITEM_STRIDE : J; }
 constexpr int MAX_ITEMS = 896;      // n_item limit of the engine
 
 // parameter block written by the tiny step (fp64): a, b, lambda, sig2t, rho : 5 x J, then Sigp(4), beta(2*PMAX),
