@@ -1594,8 +1594,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 // is kept as three per-lane partial sums -- -max(s, 0) with s = eta or -eta by y, the PRODUCT of the factors 1 + e^{-|eta|} (each in
                 // (1, 2]: one logarithm per lane at the end, or every 512 factors), and sum er^2 / sig2t_j -- and the per-item constants enter
                 // once, times the number of cells.
-                double lmax = 0.0, bprod = 1.0, rtq = 0.0;
-                int ncells = 0, nfac = 0;
+                double lmax = 0.0, bprod = 1.0, rtq = 0.0, asum = 0.0;
+                int ncells = 0, nfac = 0, ny0 = 0, ny1 = 0;
                 for (int bt = nbatch - 1 - ((nbatch - 1 - wave) % nWaves + nWaves) % nWaves; bt >= 0; bt -= nWaves) {      // a batch: 2 slots x 2 half-waves = 4 subjects, 4 cells per lane
                     double thv[2], zev[2]; double2 wv[2], cv[2]; unsigned int yv[2]; bool okv[2];
                     const int q0 = 4 * bt + 3;                         // the batch's last subject (position in the workgroup); rows beyond the workgroup's are masked
@@ -1621,13 +1621,16 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                     for (int u = 0; u < 2; ++u) {
                         if (!okv[u]) continue;
                         const double th = thv[u], ze = zev[u], th2 = th * th, hth = 0.5 * th;
-                        auto cell = [&](double w, bool y, double c, double a, double b, double lamc, double isig, double* S) {
+                        auto cell = [&](double w, bool y, double c, double a, double b, double lamc, double isig, double* S, int& ny) {
                             S[0] += w; S[1] = fma(w, th, S[1]); S[2] = fma(w, th2, S[2]); S[3] += y ? hth : -hth;
                             if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) S[4] = fma(c, ze, S[4]);
                             if (A.mode == 1) {
+                                // y eta - max(eta, 0) = -max(s, 0) with s = (1 - 2y) eta = -2 kappa eta, and max(s, 0) = (|eta| + s) / 2: the sum over a lane's cells is
+                                // sum |eta| / 2 - sum kappa eta, and sum kappa eta = a_j (sum kappa theta - b_j sum kappa) comes from S[3] and the count of ones --
+                                // one add (|eta| is an operand modifier) and a count per cell instead of a sign flip, a select, a maximum and an add
                                 const double eta = a * (th - b);
-                                const double sgn = y ? -eta : eta;                  // y eta - max(eta, 0) = -max(sgn, 0)
-                                lmax += sgn > 0.0 ? sgn : 0.0;
+                                asum += fabs(eta);
+                                ny += y ? 1 : 0;
                                 bprod *= 1.0 + fm::exp_neg_ll(fabs(eta));
                                 if constexpr (!RTLL && (fam_rt(MODEL) || fam_lq(MODEL))) {
                                     const double er = c + ze - lamc;
@@ -1635,8 +1638,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                                 }
                             }
                         };
-                        cell(wv[u].x, (yv[u] & 0xFFu) != 0u, cv[u].x, a0, b0, lamc0, isig0, S0);
-                        cell(wv[u].y, (yv[u] >> 8) != 0u, cv[u].y, a1, b1, lamc1, isig1, S1);
+                        cell(wv[u].x, (yv[u] & 0xFFu) != 0u, cv[u].x, a0, b0, lamc0, isig0, S0, ny0);
+                        cell(wv[u].y, (yv[u] >> 8) != 0u, cv[u].y, a1, b1, lamc1, isig1, S1, ny1);
                         ++ncells;
                     }
                     nfac += 4;
@@ -1644,7 +1647,9 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                 }
                 double llc = 0.0;
                 if (A.mode == 1) {
-                    llc = -(lmax + fm::log(bprod, logtab));
+                    const double hn = 0.5 * (double)ncells;
+                    const double sketa = fma(a0, fma(-b0, (double)ny0 - hn, S0[3]), a1 * fma(-b1, (double)ny1 - hn, S1[3]));      // sum kappa eta of this lane's cells (S[3]: before the half-waves are added)
+                    llc = -(fma(0.5, asum, -sketa) + lmax + fm::log(bprod, logtab));
                     if constexpr (!RTLL && (fam_rt(MODEL) || fam_lq(MODEL))) llc -= 0.5 * (rtq + (double)ncells * (2.0 * LOG_2PI + lsig0 + lsig1));
                 }
 #pragma unroll

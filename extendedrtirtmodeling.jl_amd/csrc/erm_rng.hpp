@@ -161,8 +161,7 @@ __device__ __forceinline__ double exp_neg_ll(double a)
 {
     a = a < 700.0 ? a : 700.0;
     const double k = __builtin_rint(a * -1.44269504088896340736);
-    double r = fma(k, 0.693147180559945286227, a);
-    r = fma(k, 2.31904681384629955842e-17, r);
+    const double r = fma(k, 0.693147180559945286227, a);          // (without the low word of ln 2: it moves e^{-a} by |k| 2.3e-17 relative, i.e. the factor 1 + e^{-a} by < 1.2e-17)
     const double t = -r;
     double P = 0x1.af6326f3df789p-26;
     P = fma(P, t, 0x1.28b40d95cf927p-22); P = fma(P, t, 0x1.71ddf56f3c074p-19); P = fma(P, t, 0x1.a01991a3c8c2ep-16); P = fma(P, t, 0x1.a01a01b1457b9p-13);
