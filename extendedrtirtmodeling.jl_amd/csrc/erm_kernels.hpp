@@ -2467,6 +2467,8 @@ __global__ void sample_batch_kernel(int which, uint64_t seed, uint32_t site, uin
     switch (which) {
     case 15: v = fm::log(par0[k], sh_logtab); break;           // the table form of the cell path's logarithm
     case 16: v = fm::cos2pi(par0[k]); break;
+    case 18: v = fm::exp_neg_ll(par0[k]); break;               // the cell log-likelihood's form of e^{-a}
+    case 19: v = fm::log_word((uint32_t)par0[k], sh_logtab); break;      // log((w + 1/2) 2^-32) of the word par0 stands for (the PG attempt's -log u1)
     case 0: v = (double)uniform<real>(st); break;
     case 1: v = (double)normal<real>(st); break;
     case 2: v = (double)expo<real>(st); break;

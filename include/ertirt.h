@@ -231,7 +231,8 @@ int erm_abi_version(void);
  * tests to compare the device restatement of each sampler with the oracle.  which: 0 uniform, 1 normal, 2 expo,
  * 3 PG(1, par0), 4 IG(par0, par1), 5 TN(par0, par1; 0, inf), 6 Gamma(par0), 7 PG mixture weight(par0), 8 QR weight(par0, par1),
  * 9 normal quantile(par0), 10 PG(1, par0) through the reference form of the attempt (fp64: every decision in fp64),
- * 11-14 the fp64 cell path's log(par0), exp(-par0), sqrt(par0), par0 / par1; 15 its table-driven log(par0), 16 cos(2 pi par0), 17 its form of the QR weight (par0 = |residual|, par1 = parB at unit scale: the same variate as 8). */
+ * 11-14 the fp64 cell path's log(par0), exp(-par0), sqrt(par0), par0 / par1; 15 its table-driven log(par0), 16 cos(2 pi par0), 17 its form of the QR weight (par0 = |residual|, par1 = parB at unit scale: the same variate as 8),
+ * 18 the cell log-likelihood's exp(-par0), 19 log((w + 1/2) 2^-32) of the 32-bit word w = par0 (the PG attempt's logarithm of a uniform). */
 int erm_debug_sample(int device, int precision, int which, uint64_t seed, uint32_t site, uint32_t sweep, int64_t n,
                      const double* par0, const double* par1, double* out);
 

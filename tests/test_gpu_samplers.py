@@ -78,6 +78,11 @@ def test_fp64_cell_path_elementary_functions():
     d = _dev(12, a.size, a)
     ref = np.exp(-np.minimum(a, 700.0))
     assert np.max(np.abs(d - ref) / ref) < 2e-15
+    d = _dev(18, a.size, a)                                     # the cell log-likelihood's shorter polynomial: absolute accuracy on a value that is added to 1
+    assert np.max(np.abs(d - ref)) < 3e-16 and np.max(np.abs(d - ref) / ref) < 4e-14
+    w = np.concatenate([g.integers(0, 2 ** 32, N), np.arange(0, 4096), 2 ** 32 - 1 - np.arange(0, 4096), 2 ** np.arange(0, 32)]).astype(np.float64)
+    d = _dev(19, w.size, w)                                     # -log u1 of a PG attempt straight from its word: the same bits as the table logarithm of the uniform
+    assert np.array_equal(d, _dev(15, w.size, (w + 0.5) * 2.0 ** -32))
     d = _dev(13, x.size, x)
     assert np.max(np.abs(d - np.sqrt(x)) / np.sqrt(x)) < 3e-16
     u = np.concatenate([g.uniform(0, 1, N), (np.arange(0, 4097) / 4096.0), (np.arange(0, 2 ** 12) + 0.5) * 2.0 ** -32, 1 - (np.arange(0, 2 ** 12) + 0.5) * 2.0 ** -32])
