@@ -2287,11 +2287,15 @@ __global__ void center_kernel(real* C, long long N, int J, const double* mean, d
 //   run_begin_kernel : both copies of the chain's counters, the group tickets zeroed, the persistent launch's wait bound and test hook;
 //   run_end_kernel   : the counters of both buffers and the time-out word into PINNED HOST memory (visible to the host once the stream has drained).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) run_begin_kernel(Ctl* c0, Ctl* c1, Ctl v, unsigned int* gcnt, int n_gcnt, unsigned int tmo_ticks, unsigned int tmo_fault)
+// (the call's parameters come from PINNED HOST memory the host fills before it enqueues the call: the kernel's arguments never change, so it can sit at the head of a
+// replayed graph that holds the whole call -- erm_run: whole_graph)
+struct RunParams { Ctl v; unsigned int tmo_ticks, tmo_fault; };
+__global__ void __launch_bounds__(256) run_begin_kernel(Ctl* c0, Ctl* c1, const RunParams* hp, unsigned int* gcnt, int n_gcnt)
 {
     const int t = (int)threadIdx.x;
-    if (t == 0) { *c0 = v; *c1 = v; }
-    for (int k = t; k < n_gcnt; k += (int)blockDim.x) gcnt[k] = (k == n_gcnt - 3) ? tmo_ticks : ((k == n_gcnt - 2) ? tmo_fault : 0u);      // [tickets | tmo flag, ticks, fault, pad]
+    const RunParams rp = *hp;
+    if (t == 0) { *c0 = rp.v; *c1 = rp.v; }
+    for (int k = t; k < n_gcnt; k += (int)blockDim.x) gcnt[k] = (k == n_gcnt - 3) ? rp.tmo_ticks : ((k == n_gcnt - 2) ? rp.tmo_fault : 0u);      // [tickets | tmo flag, ticks, fault, pad]
 }
 __global__ void __launch_bounds__(64) run_end_kernel(const Ctl* c0, const Ctl* c1, const unsigned int* tmo, Ctl* host_out, unsigned int* host_tmo)
 {

@@ -207,6 +207,7 @@ template <typename real> struct Engine : EngineBase {
         if (comm) (void)g_rccl.CommDestroy(comm);
         for (auto e : pass_ev) (void)hipEventDestroy(e);
         if (host_ctl) (void)hipHostFree(host_ctl);
+        if (host_run) (void)hipHostFree(host_run);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -264,6 +265,8 @@ template <typename real> struct Engine : EngineBase {
         HIPCHK(hipEventCreate(&ev1));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_ctl), 4 * sizeof(Ctl), hipHostMallocDefault));      // [1], [2]: the two device copies of the counters, [3]: a persistent launch's time-out word -- written by run_end_kernel
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_ctl_dev), host_ctl, 0));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&host_run), sizeof(RunParams), hipHostMallocDefault));      // an erm_run's parameters, read by run_begin_kernel
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_run_dev), host_run, 0));
 
         // ---- geometry (pure host function, CPU-tested: erm_geometry.hpp)
         {
@@ -563,7 +566,15 @@ template <typename real> struct Engine : EngineBase {
     // run starts from buffer 0 and replays its graphs BEFORE its one single sweep)
     const int graph_sweeps[NGRAPH] = {GRAPH_SWEEPS, 16, 4, 2};
     hipGraphExec_t graphs[NGRAPH] = {nullptr, nullptr, nullptr, nullptr};
-    void drop_graphs() { for (auto& g : graphs) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; } }
+    // A WHOLE call as graphs (single-pass and Cross samplers on the per-sweep schedule, statistics resident): calls of up to GRAPH_SWEEPS sweeps are ONE graph --
+    // run_begin_kernel, the sweeps, the closing tiny step and run_end_kernel (full[k]) --, longer ones (and, in profile mode, every call: its event bracket goes around
+    // graph launches) end in tail[r] = r sweeps + tiny step + run_end_kernel behind their blocks of GRAPH_SWEEPS.  Between a graph and an ordinary launch
+    // the device idles 10-14 us (measured: tools/run_timeline.py), inside a graph 0: a 20-sweep call 1 435 -> 1 400 us of device time.  Built by the first call of each length.
+    hipGraphExec_t graphs_full[GRAPH_SWEEPS + 1] = {}, graphs_tail[GRAPH_SWEEPS + 1] = {};
+    void drop_graphs() {
+        for (auto& g : graphs) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; }
+        for (auto* arr : {graphs_full, graphs_tail}) for (int k = 0; k <= GRAPH_SWEEPS; ++k) { if (arr[k]) (void)hipGraphExecDestroy(arr[k]); arr[k] = nullptr; }
+    }
     bool ev_calibrated = false; double ev_null_ms = 0.0;
     template <int MODEL> int enqueue_sweep(bool timed) {
         if constexpr (!fam_cq(MODEL)) { if (fused()) return launch_fused<MODEL>(timed); }
@@ -575,12 +586,23 @@ template <typename real> struct Engine : EngineBase {
         }
         return 0;
     }
-    template <int MODEL> int build_graph(int nsw, hipGraphExec_t* out) {
+    void launch_run_begin() {
+        hipLaunchKernelGGL(run_begin_kernel, dim3(1), dim3(256), 0, stream, dCtlB[0].template as<Ctl>(), dCtlB[1].template as<Ctl>(), host_run_dev, dGcnt.as<unsigned int>(), 2 * n_groups + 4);
+    }
+    void launch_run_end() {
+        hipLaunchKernelGGL(run_end_kernel, dim3(1), dim3(64), 0, stream, dCtlB[0].template as<Ctl>(), dCtlB[1].template as<Ctl>(), dGcnt.as<unsigned int>() + 2 * n_groups,
+                           host_ctl_dev + 1, reinterpret_cast<unsigned int*>(host_ctl_dev + 3));
+    }
+    // nsw sweeps; `begin`: run_begin_kernel first; `end`: the closing tiny step and run_end_kernel last.
+    // The capture starts at buffer parity 0 (every call does) and -- a graph is only ever replayed at that parity -- restores it afterwards.
+    template <int MODEL> int build_graph(int nsw, hipGraphExec_t* out, bool begin = false, bool end = false) {
         hipGraph_t g = nullptr;
-        const int cur0 = cur;                        // a fused sweep flips the double buffers while it is being captured: nsw is even, but a
-        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));       // failed capture must not leave the parity changed
+        const int cur0 = cur;                        // a fused sweep flips the double buffers while it is being captured: a failed capture -- and a whole-call
+        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));       // graph, whose sweeps the caller does not count -- must not leave the parity changed
         int rc = 0;
+        if (begin) launch_run_begin();
         for (int k = 0; k < nsw && !rc; ++k) rc = enqueue_sweep<MODEL>(false);
+        if (end && !rc) { rc = launch_tiny<MODEL, 0>(1); launch_run_end(); }
         const hipError_t e = hipStreamEndCapture(stream, &g);      // always ends the capture, also after a failed enqueue
         if (!rc && e != hipSuccess) rc = fail(ERM_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         if (!rc) {
@@ -588,10 +610,12 @@ template <typename real> struct Engine : EngineBase {
             if (ei != hipSuccess) { *out = nullptr; rc = fail(ERM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
         }
         if (g) (void)hipGraphDestroy(g);             // on every exit
-        if (rc) cur = cur0;
+        if (rc || end) cur = cur0;                   // (a whole-call graph: run_model moves the parity when it replays it)
         return rc;
     }
-    template <int MODEL> int run_model(int64_t nsweeps) {
+    // whole: 0 = the caller launches run_begin_kernel / run_end_kernel around this; 1 = the call is ONE graph (built by the caller: graphs_full[_ev][nsweeps]);
+    // 2 = run_begin_kernel is enqueued, the call's last graph (graphs_tail) carries the closing tiny step and run_end_kernel
+    template <int MODEL> int run_model(int64_t nsweeps, int whole = 0) {
         // prologue: omega_{t+1} (and nu_{t+1}) and the statistics of the current state.  A run that CONTINUES the previous one finds both
         // in place -- the last pass drew omega_{t+1} from the same addressed streams and left the same statistics -- and skips it.
         if (!stats_valid) {
@@ -620,6 +644,37 @@ template <typename real> struct Engine : EngineBase {
         // parity) before every replayed block of a long one.
         const bool graph_timing = cfg.profile && !fam_cq(MODEL) && fused() && !sharded();
         const bool single_timing = cfg.profile && !graph_timing;
+        const bool flips = !fam_cq(MODEL) && fused();      // a fused sweep flips the double buffers (launch_fused); the two-kernel schedules do not
+        if (whole == 1) {
+            HIPCHK(hipGraphLaunch(graphs_full[nsweeps], stream));
+            if (flips) cur = (int)((cur + nsweeps) & 1);
+            return 0;
+        }
+        if (whole == 2) {
+            const int r = (nsweeps % GRAPH_SWEEPS) == 0 ? GRAPH_SWEEPS : (int)(nsweeps % GRAPH_SWEEPS);
+            if (nsweeps > r && !graphs[0]) { if (int rc = build_graph<MODEL>(GRAPH_SWEEPS, &graphs[0])) return rc; }
+            if (!graphs_tail[r]) { if (int rc = build_graph<MODEL>(r, &graphs_tail[r], false, true)) return rc; }
+            int in_bracket = 0, launches = 0;
+            bool open = false;
+            auto close = [&]() -> int {
+                if (!open) return 0;
+                HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream));
+                ++n_brackets; n_pass_timed += launches; bracket_launches.push_back(launches);
+                open = false; in_bracket = 0; launches = 0;
+                return 0;
+            };
+            auto replay = [&](hipGraphExec_t g, int nsw) -> int {
+                if (graph_timing && !open && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size()) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream)); open = true; }
+                HIPCHK(hipGraphLaunch(g, stream));
+                k += nsw; launches += nsw; ++in_bracket;
+                if (in_bracket >= 4) return close();
+                return 0;
+            };
+            while (nsweeps - k > r) { if (int rc = replay(graphs[0], GRAPH_SWEEPS)) return rc; }
+            if (int rc = replay(graphs_tail[r], r)) return rc;      // (its bracket also holds the closing tiny step and run_end_kernel: ~8 us once per call)
+            if (flips) cur = (int)((cur + r) & 1);
+            return close();
+        }
         if (use_graph && !single_timing) {
             bool open = false;
             int in_bracket = 0, launches = 0;
@@ -698,6 +753,8 @@ template <typename real> struct Engine : EngineBase {
     bool stats_valid = false;                        // omega_{t+1} (nu_{t+1}) and the statistics of the CURRENT state are resident (set by a completed run)
     Ctl* host_ctl = nullptr;                         // pinned: [1], [2] the two device copies of the counters, [3] the time-out word (run_end_kernel stores them)
     Ctl* host_ctl_dev = nullptr;                     // the same memory as the device addresses it
+    RunParams* host_run = nullptr;                   // pinned: the parameters of the erm_run being enqueued (run_begin_kernel reads them)
+    RunParams* host_run_dev = nullptr;
     bool has_stats_state() const { return host_ctl != nullptr; }
     int run(int64_t nsweeps) override {
         if (!has_data) return fail(ERM_ERR_STATE, "erm_set_data has not been called");
@@ -738,14 +795,24 @@ template <typename real> struct Engine : EngineBase {
             cur = 0;
         }
         const bool persistent_run = persist && !sharded() && nsweeps > 0 && !m_cq();
-        // counters, tickets, the persistent launch's wait bound (1 s of the 100 MHz wall clock; 2 ms under the test hook) in ONE small launch
+        // counters, tickets, the persistent launch's wait bound (1 s of the 100 MHz wall clock; 2 ms under the test hook) in ONE small launch, its parameters in pinned memory
         const bool fault = persistent_run && persist_fault_countdown > 0 && --persist_fault_countdown == 0;
-        hipLaunchKernelGGL(run_begin_kernel, dim3(1), dim3(256), 0, stream, dCtlB[0].template as<Ctl>(), dCtlB[1].template as<Ctl>(), c, dGcnt.as<unsigned int>(), 2 * n_groups + 4,
-                           fault ? 200000u : 100000000u, fault ? 1u : 0u);
-        HIPCHK(hipGetLastError());
-        if (persistent_run) { snap_stats_valid = stats_valid; if (int rc = snap_copy(false)) return rc; }
+        host_run->v = c; host_run->tmo_ticks = fault ? 200000u : 100000000u; host_run->tmo_fault = fault ? 1u : 0u;
+        volatile unsigned int* h_tmo = reinterpret_cast<volatile unsigned int*>(&host_ctl[3]);
+        *h_tmo = 0u;
         n_pass_timed = 0; n_brackets = 0; bracket_launches.clear();
         const bool calibrate = cfg.profile && pass_ev.size() >= 64 && !ev_calibrated;
+        // the whole call as graphs (see graphs_full): per-sweep schedule, statistics resident, nothing that has to be bracketed launch by launch
+        const bool graph_timing = cfg.profile && !m_cq() && fused() && !sharded();
+        int whole = 0;
+        if (exch == nullptr && (cfg.flags & ERM_FLAG_NO_GRAPH) == 0 && !sharded() && !persistent_run && stats_valid && !calibrate && nsweeps >= 1 && !(cfg.profile && !graph_timing))
+            whole = (nsweeps <= GRAPH_SWEEPS && !graph_timing) ? 1 : 2;      // (profile mode: the bracket's events stay on the stream, around the call's graphs -- event
+                                                                             // records captured INTO a graph do not time its kernels on this runtime: tried, 13.9 us per sweep)
+        if (whole == 1 && !graphs_full[nsweeps]) {
+            if (int rcb = dispatch([&](auto m) -> int { return build_graph<decltype(m)::value>((int)nsweeps, &graphs_full[nsweeps], true, true); })) return rcb;
+        }
+        if (whole != 1) { launch_run_begin(); HIPCHK(hipGetLastError()); }
+        if (persistent_run) { snap_stats_valid = stats_valid; if (int rc = snap_copy(false)) return rc; }
         if (calibrate) {   // empty event pairs, once per engine: the bracketing overhead that is subtracted from every timed launch
             for (int k = 0; k < 16; ++k) { HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 2 - 2 * k], stream)); HIPCHK(hipEventRecord(pass_ev[pass_ev.size() - 1 - 2 * k], stream)); }
         }
@@ -753,15 +820,11 @@ template <typename real> struct Engine : EngineBase {
         std::unique_lock<std::mutex> turn;
         if (persistent_run) turn = std::unique_lock<std::mutex>(g_persist_mu[(unsigned)cfg.device % 64u]);
         HIPCHK(hipEventRecord(ev0, stream));
-        if (int rc = dispatch([&](auto m) -> int { return run_model<decltype(m)::value>(nsweeps); })) return rc;
+        if (int rc = dispatch([&](auto m) -> int { return run_model<decltype(m)::value>(nsweeps, whole); })) return rc;
         HIPCHK(hipEventRecord(ev1, stream));
         HIPCHK(hipGetLastError());
-        // the counters of both buffers and the time-out word, stored into pinned host memory by one small launch (no copy operations)
-        volatile unsigned int* h_tmo = reinterpret_cast<volatile unsigned int*>(&host_ctl[3]);
-        *h_tmo = 0u;
-        hipLaunchKernelGGL(run_end_kernel, dim3(1), dim3(64), 0, stream, dCtlB[0].template as<Ctl>(), dCtlB[1].template as<Ctl>(), dGcnt.as<unsigned int>() + 2 * n_groups,
-                           host_ctl_dev + 1, reinterpret_cast<unsigned int*>(host_ctl_dev + 3));
-        HIPCHK(hipGetLastError());
+        // the counters of both buffers and the time-out word, stored into pinned host memory by one small launch (no copy operations; inside the call's last graph when it has one)
+        if (!whole) { launch_run_end(); HIPCHK(hipGetLastError()); }
         HIPCHK(hipStreamSynchronize(stream));
         if (turn.owns_lock()) turn.unlock();
         if (*h_tmo != 0u) {
