@@ -567,8 +567,8 @@ template <typename real> struct Engine : EngineBase {
     const int graph_sweeps[NGRAPH] = {GRAPH_SWEEPS, 16, 4, 2};
     hipGraphExec_t graphs[NGRAPH] = {nullptr, nullptr, nullptr, nullptr};
     // A WHOLE call as graphs (single-pass and Cross samplers on the per-sweep schedule, statistics resident): calls of up to GRAPH_SWEEPS sweeps are ONE graph --
-    // run_begin_kernel, the sweeps, the closing tiny step and run_end_kernel (full[k]) --, longer ones (and, in profile mode, every call: its event bracket goes around
-    // graph launches) end in tail[r] = r sweeps + tiny step + run_end_kernel behind their blocks of GRAPH_SWEEPS.  Between a graph and an ordinary launch
+    // run_begin_kernel, the sweeps, the closing tiny step and run_end_kernel (full[k]) --, longer ones end in tail[r] = r sweeps + tiny step + run_end_kernel behind
+    // their blocks of GRAPH_SWEEPS.  Between a graph and an ordinary launch
     // the device idles 10-14 us (measured: tools/run_timeline.py), inside a graph 0: a 20-sweep call 1 435 -> 1 400 us of device time.  Built by the first call of each length.
     hipGraphExec_t graphs_full[GRAPH_SWEEPS + 1] = {}, graphs_tail[GRAPH_SWEEPS + 1] = {};
     void drop_graphs() {
@@ -646,7 +646,13 @@ template <typename real> struct Engine : EngineBase {
         const bool single_timing = cfg.profile && !graph_timing;
         const bool flips = !fam_cq(MODEL) && fused();      // a fused sweep flips the double buffers (launch_fused); the two-kernel schedules do not
         if (whole == 1) {
+            // (profile mode: the bracket's events go around the graph on the stream -- event records captured INTO a graph do not time its kernels on this runtime:
+            // tried, 13.9 us per sweep -- so it also holds the three small kernels, ~12 us per call; as two launches, run_begin_kernel and a tail graph, it held the
+            // 10.7 us gap between them instead of the 3.5 us kernel)
+            const bool ev = graph_timing && (size_t)(2 * n_brackets + 1) + 64 < pass_ev.size();
+            if (ev) HIPCHK(hipEventRecord(pass_ev[2 * n_brackets], stream));
             HIPCHK(hipGraphLaunch(graphs_full[nsweeps], stream));
+            if (ev) { HIPCHK(hipEventRecord(pass_ev[2 * n_brackets + 1], stream)); ++n_brackets; n_pass_timed += nsweeps; bracket_launches.push_back((int)nsweeps); }
             if (flips) cur = (int)((cur + nsweeps) & 1);
             return 0;
         }
@@ -806,8 +812,7 @@ template <typename real> struct Engine : EngineBase {
         const bool graph_timing = cfg.profile && !m_cq() && fused() && !sharded();
         int whole = 0;
         if (exch == nullptr && (cfg.flags & ERM_FLAG_NO_GRAPH) == 0 && !sharded() && !persistent_run && stats_valid && !calibrate && nsweeps >= 1 && !(cfg.profile && !graph_timing))
-            whole = (nsweeps <= GRAPH_SWEEPS && !graph_timing) ? 1 : 2;      // (profile mode: the bracket's events stay on the stream, around the call's graphs -- event
-                                                                             // records captured INTO a graph do not time its kernels on this runtime: tried, 13.9 us per sweep)
+            whole = nsweeps <= GRAPH_SWEEPS ? 1 : 2;
         if (whole == 1 && !graphs_full[nsweeps]) {
             if (int rcb = dispatch([&](auto m) -> int { return build_graph<decltype(m)::value>((int)nsweeps, &graphs_full[nsweeps], true, true); })) return rcb;
         }
