@@ -1,3 +1,4 @@
+# lanes-per-row probe (GPU box, repo root): the headline workload at W = 8 / 4 / 2 / 16 lanes per subject in the row-sum phase, twice
 mkdir -p gpurun_out/r4
 for k in 1 2; do for w in 8 4 2 16; do python bench.py --steps 300 --warmup 30 --no-two-chains --cpu-sweeps 0 --lanes-per-row $w 2>/dev/null | python -c "
 import sys,json
