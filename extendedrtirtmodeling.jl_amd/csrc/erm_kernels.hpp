@@ -1624,7 +1624,8 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                         auto cell = [&](double w, bool y, double c, double a, double b, double lamc, double isig, double* S, int& ny) {
                             S[0] += w; S[1] = fma(w, th, S[1]); S[2] = fma(w, th2, S[2]); S[3] += y ? hth : -hth;
                             if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) S[4] = fma(c, ze, S[4]);
-                            if (A.mode == 1) {
+                            {   // (also in the statistics-only pass that opens a chain, A.mode == 0, which discards it: a test of the mode here is a branch per cell and
+                                // a basic-block boundary between the four cells' independent polynomial chains)
                                 // y eta - max(eta, 0) = -max(s, 0) with s = (1 - 2y) eta = -2 kappa eta, and max(s, 0) = (|eta| + s) / 2: the sum over a lane's cells is
                                 // sum |eta| / 2 - sum kappa eta, and sum kappa eta = a_j (sum kappa theta - b_j sum kappa) comes from S[3] and the count of ones --
                                 // one add (|eta| is an operand modifier) and a count per cell instead of a sign flip, a select, a maximum and an add
@@ -1712,7 +1713,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                         auto cell = [&](float w, bool y, float c, float a, float b, float lamc, float isig, float* bs) {
                             bs[0] += w; bs[1] = fmaf(w, th, bs[1]); bs[2] = fmaf(w, th2, bs[2]); bs[3] += y ? hth : -hth;
                             if constexpr (fam_rt(MODEL) || fam_lq(MODEL)) bs[4] = fmaf(c, ze, bs[4]);
-                            if (A.mode == 1) {
+                            {   // (in every mode, as in the fp64 loop: no branch per cell)
                                 const float eta = a * (th - b);
                                 float t = (y ? eta : 0.0f) - log1pexp_r(eta);
                                 if constexpr (!RTLL && (fam_rt(MODEL) || fam_lq(MODEL))) {
@@ -1738,7 +1739,7 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
                     for (int q = 0; q < NSTAT; ++q) { acc[q * J + j0] = S0[q]; acc[q * J + j0 + 1] = S1[q]; }
                     if constexpr (RTLL) { if (A.mode == 1) llc = fma(-(double)isig1, S1[4], fma(-(double)isig0, S0[4], llc)); }
                 }
-                ll += llc;
+                if (A.mode == 1) ll += llc;
             }
         }
     }
