@@ -1341,9 +1341,9 @@ __global__ void __launch_bounds__(PERSIST ? PERSIST_THREADS : max_block_threads(
         if (active) cell_words(rr, j);
         [[maybe_unused]] unsigned int n_att = 0, n_trip = 0;
 #ifndef ERM_PG_VKEYS
-#define ERM_PG_VKEYS 8
+#define ERM_PG_VKEYS 20      // (8 until the end of round 4; with two rounds of the block hoisted out of the attempt the loop has the registers for all of them: 67.8 -> 67.6 us, 6 / 12 lose)
 #endif
-        constexpr int NVK = PERSIST ? 20 : ERM_PG_VKEYS;         // round keys of the attempts' Philox blocks kept in vector registers (philox4x32_10_vk); the persistent kernel has 256 VGPRs: all twenty
+        constexpr int NVK = PERSIST ? 20 : ERM_PG_VKEYS;         // round keys of the attempts' Philox blocks kept in vector registers (philox4x32_10_vk)
         uint32_t pgk[NVK > 0 ? NVK : 1];
         philox_vector_keys<NVK>((uint32_t)A.seed, (uint32_t)(A.seed >> 32), pgk);
         // (letting a wave whose queue ran dry serve other waves' queues was tried: the hardware favours a SIMD's oldest wave, so the
